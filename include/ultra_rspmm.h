@@ -1,0 +1,124 @@
+/*
+ * include/ultra_rspmm.h -- C ABI of libultra_rspmm.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the one native operator on the reference's hot path:
+ *
+ *     torchdrug.layers.functional.generalized_rspmm(sparse, relation, input, sum=..., mul=...)
+ *
+ * called from /root/reference/ultra/layer.py:134-167 (relation-graph stack) and :336-369 (entity
+ * stack).  In torchdrug that Python function dispatches to the C++/CUDA extension entry points
+ * rspmm_{add,min,max}_{mul,add}_{forward,backward}_{cpu,cuda}(sparse, relation, input[, output,
+ * output_grad]) (torchdrug/layers/functional/extension/rspmm.{h,cpp,cu}, un-vendored).
+ * The functions below are what a binding for that path would bind instead: plain device pointers and
+ * sizes, no torch types.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host;
+ *  - all tensors are dense row-major fp32, indices are int32;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only enqueues
+ *    work on that stream: no allocation, no host synchronisation, hipGraph-capture safe;
+ *  - return value: 0 on success, otherwise an ultra_status code (ultra_rspmm_status_string()).
+ *
+ * Reduction plan ("segments").  One call reduces, for every target row t, an ordered list of
+ * contributions.  The three plans of a graph differ only in what a row and a contribution are:
+ *    forward      rows = destination nodes   sorted by (dst, src, rel)   (the coalesced CSR torchdrug builds)
+ *    d_input      rows = source nodes        sorted by (src, dst, rel)
+ *    d_relation   rows = relations           sorted by (rel, dst, src)
+ * A plan cuts the sorted edge list into chunks: a chunk is either a run of whole rows or one piece
+ * (<= piece_len consecutive edges) of a row longer than piece_len.  Pieces are summed into a
+ * workspace and added in piece order by a second kernel, so results never depend on scheduling.
+ */
+#ifndef ULTRA_RSPMM_H
+#define ULTRA_RSPMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ULTRA_RSPMM_ABI_VERSION 1
+
+/* sum= / mul= of generalized_rspmm (layer.py:134-167: sum in {"add","max","min"}, mul in {"mul","add"}) */
+enum ultra_sum_op { ULTRA_SUM_ADD = 0, ULTRA_SUM_MIN = 1, ULTRA_SUM_MAX = 2 };
+enum ultra_mul_op { ULTRA_MUL_MUL = 0, ULTRA_MUL_ADD = 1 };
+
+enum ultra_status {
+    ULTRA_OK = 0,
+    ULTRA_ERR_BAD_OP = 1,        /* unknown sum/mul code (the Python side raises ValueError first) */
+    ULTRA_ERR_BAD_SHAPE = 2,     /* F not a multiple of 64, negative sizes, index range overflow */
+    ULTRA_ERR_NULL_POINTER = 3,
+    ULTRA_ERR_WORKSPACE = 4,     /* workspace smaller than ultra_rspmm_workspace_bytes() */
+    ULTRA_ERR_HIP = 5,           /* a HIP runtime call failed; see ultra_rspmm_last_hip_error() */
+    ULTRA_ERR_NO_DEVICE = 6      /* no gfx950 device visible */
+};
+
+/* One ordered reduction plan over the edge list (all arrays in device memory, built once per graph). */
+typedef struct ultra_segments {
+    int64_t n_rows;            /* number of target rows of this plan                                   */
+    int64_t n_edges;           /* coalesced edge count E                                                */
+    const int32_t *row;        /* [E] target row of each edge, non-decreasing                           */
+    const int32_t *node_a;     /* [E] forward: src node | d_input: dst node | d_relation: src node      */
+    const int32_t *node_b;     /* [E] forward: unused   | d_input: unused   | d_relation: dst node      */
+    const int32_t *rel;        /* [E] relation id                                                       */
+    const float *weight;       /* [E] edge weight, or NULL when every weight is exactly 1.0f            */
+    int64_t n_chunks;          /* number of schedule entries                                            */
+    const int32_t *chunks;     /* [n_chunks][4]: {edge_begin, edge_end, row_begin, row_end}; a piece of */
+                               /*   a long row stores row_end = -(piece_slot + 1)                       */
+    int64_t n_long_rows;       /* rows split into pieces                                                */
+    const int32_t *long_rows;  /* [n_long_rows][3]: {row, first_piece_slot, n_pieces}                   */
+    int64_t n_pieces;          /* total piece slots (workspace rows)                                    */
+    int64_t piece_len;         /* contributions per piece                                               */
+} ultra_segments;
+
+int ultra_rspmm_abi_version(void);
+const char *ultra_rspmm_status_string(int status);
+/* hipError_t of the last failing HIP call on this thread (0 if none). */
+int ultra_rspmm_last_hip_error(void);
+
+/* Fills n_cu (compute units), lds_bytes (per workgroup limit), arch (e.g. "gfx950", buffer >= 32 B). */
+int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_host, size_t arch_len);
+
+/* Scratch bytes a call over `seg` with row width F needs (piece partial sums). */
+size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg_host, int64_t F);
+
+/*
+ * out[v, :] = SUM_{(u, v, r, w) in row v}  w * (relation[r, :] MUL input[u, :])
+ * replaces rspmm_{sum}_{mul}_forward_cuda(sparse, relation, input)      [layer.py:134-167,336-369]
+ *   fwd       : forward plan;  relation [n_rel, F];  input [n_src, F];  out [fwd->n_rows, F]
+ *   add_rows  : optional [n_rows, F] or NULL.  When given, the epilogue the reference applies right
+ *               after the call is fused: sum=add -> out + add_rows (layer.py:156,358),
+ *               sum=max -> max(out, add_rows) (layer.py:162,364), sum=min -> min(out, add_rows).
+ * Empty rows give 0 (add), +inf (min), -inf (max).
+ */
+int ultra_rspmm_forward_f32(const ultra_segments *fwd_host, const float *relation, const float *input,
+                            const float *add_rows, float *out, void *workspace, size_t workspace_bytes,
+                            int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream);
+
+/*
+ * Gradients of the call above w.r.t. input and relation
+ * replaces rspmm_{sum}_{mul}_backward_cuda(sparse, relation, input, output, output_grad).
+ *   by_src / by_rel : the d_input / d_relation plans of the same graph
+ *   output          : forward result WITHOUT add_rows fused (only read for min/max)
+ *   output_grad     : dL/d(output) [n_dst, F]
+ *   d_input [n_src, F], d_relation [n_rel, F]: either may be NULL to skip it.
+ */
+int ultra_rspmm_backward_f32(const ultra_segments *by_src_host, const ultra_segments *by_rel_host,
+                             const float *relation, const float *input, const float *output,
+                             const float *output_grad, float *d_input, float *d_relation, void *workspace,
+                             size_t workspace_bytes, int64_t n_rel, int64_t F, int sum_op, int mul_op,
+                             void *stream);
+
+/*
+ * d_weight[e] = sum_f output_grad[dst_e, f] * [out == y] * (relation[r_e, f] MUL input[src_e, f])
+ * (the value gradient torchdrug returns when sparse.requires_grad), edges in forward-plan order.
+ */
+int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd_host, const float *relation, const float *input,
+                                    const float *output, const float *output_grad, float *d_weight,
+                                    int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULTRA_RSPMM_H */

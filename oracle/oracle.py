@@ -1,0 +1,192 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  PARITY UNPINNED (see rspmm_oracle.c).
+
+numpy + ctypes front-end of the CPU parity oracle for the rspmm hot path.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; nothing under
+``ultra_torchdrug_amd/`` does.
+
+Three independent restatements of the same operator, checked against each other in
+``tests/test_oracle.py``:
+
+* :func:`rspmm_forward` / :func:`rspmm_backward`  -- the C row loop (``rspmm_oracle.c``), i.e. the
+  torchdrug CSR algorithm the reference reaches at ``ultra/layer.py:134-167,336-369``;
+* :func:`rspmm_materialised` -- the reference's own O(E*F) definition, ``ultra/layer.py:232-296``:
+  gather ``input[node_in]``, gather ``relation_input[relation]``, combine (``:252-255``), multiply by
+  ``edge_weight`` and scatter over ``node_out`` with ``dim_size=num_node`` (``:275-285``);
+* :func:`rspmm_python` -- plain Python loops, for hand-checkable graphs only.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librspmm_oracle.so")
+
+SUM_OPS = {"add": 0, "min": 1, "max": 2}
+MUL_OPS = {"mul": 0, "add": 1}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile ``librspmm_oracle.so`` with the committed Makefile (gcc); make handles staleness."""
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_abi_version.restype = ctypes.c_int
+        for name in ("oracle_rspmm_forward", "oracle_rspmm_backward", "oracle_filtered_rank"):
+            getattr(_lib, name).restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(0)
+
+
+def _i64(v):
+    return ctypes.c_int64(int(v))
+
+
+class CSR:
+    """Coalesced CSR of the (N_dst, N_src, R) adjacency (rows = destination)."""
+
+    def __init__(self, row_ptr, col, rel, w, n_rows, n_cols, n_rel):
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        self.col = np.ascontiguousarray(col, dtype=np.int32)
+        self.rel = np.ascontiguousarray(rel, dtype=np.int32)
+        self.w = None if w is None else np.ascontiguousarray(w, dtype=np.float32)
+        self.n_rows, self.n_cols, self.n_rel = int(n_rows), int(n_cols), int(n_rel)
+
+    @property
+    def n_edges(self):
+        return int(self.col.shape[0])
+
+    @property
+    def row(self):
+        return np.repeat(np.arange(self.n_rows, dtype=np.int32), np.diff(self.row_ptr))
+
+
+def coalesce_csr(dst, src, rel, w, n_rows, n_cols, n_rel):
+    """torch ``sparse.coalesce()`` + torchdrug ``coo2csr`` [from memory]: sort the COO triples by
+    (dst, src, rel) and merge duplicate triples by summing their weights (in input order)."""
+    dst = np.asarray(dst, dtype=np.int64)
+    src = np.asarray(src, dtype=np.int64)
+    rel = np.asarray(rel, dtype=np.int64)
+    w = np.ones(dst.shape[0], dtype=np.float32) if w is None else np.asarray(w, dtype=np.float32)
+    assert dst.shape == src.shape == rel.shape == w.shape
+    if dst.size:
+        assert 0 <= dst.min() and dst.max() < n_rows and 0 <= src.min() and src.max() < n_cols
+        assert 0 <= rel.min() and rel.max() < n_rel
+    order = np.lexsort((rel, src, dst))  # stable, last key is primary
+    dst, src, rel, w = dst[order], src[order], rel[order], w[order]
+    if dst.size:
+        new = np.ones(dst.shape[0], dtype=bool)
+        new[1:] = (dst[1:] != dst[:-1]) | (src[1:] != src[:-1]) | (rel[1:] != rel[:-1])
+        starts = np.flatnonzero(new)
+        # sequential fp32 sum of the duplicates of one triple, in input order
+        wsum = np.empty(starts.shape[0], dtype=np.float32)
+        ends = np.append(starts[1:], dst.shape[0])
+        simple = (ends - starts) == 1
+        wsum[simple] = w[starts[simple]]
+        for i in np.flatnonzero(~simple):
+            acc = np.float32(0.0)
+            for k in range(starts[i], ends[i]):
+                acc = np.float32(acc + w[k])
+            wsum[i] = acc
+        dst, src, rel, w = dst[starts], src[starts], rel[starts], wsum
+    row_ptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.add.at(row_ptr, dst + 1, 1)
+    row_ptr = np.cumsum(row_ptr)
+    return CSR(row_ptr, src, rel, w, n_rows, n_cols, n_rel)
+
+
+def rspmm_forward(csr, relation, x, sum="add", mul="mul", piece=0):
+    relation = np.ascontiguousarray(relation, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    F = x.shape[1]
+    assert relation.shape == (csr.n_rel, F) and x.shape[0] == csr.n_cols
+    out = np.empty((csr.n_rows, F), dtype=np.float32)
+    rc = lib().oracle_rspmm_forward(_p(csr.row_ptr), _p(csr.col), _p(csr.rel), _p(csr.w), _p(relation), _p(x),
+                                    _p(out), _i64(csr.n_rows), _i64(csr.n_edges), _i64(csr.n_rel), _i64(F),
+                                    SUM_OPS[sum], MUL_OPS[mul], _i64(piece))
+    if rc:
+        raise RuntimeError("oracle_rspmm_forward failed: %d" % rc)
+    return out
+
+
+def rspmm_backward(csr, relation, x, out, grad, sum="add", mul="mul", piece=0, need_weight_grad=False):
+    relation = np.ascontiguousarray(relation, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.ascontiguousarray(out, dtype=np.float32)
+    grad = np.ascontiguousarray(grad, dtype=np.float32)
+    F = x.shape[1]
+    d_rel = np.empty((csr.n_rel, F), dtype=np.float32)
+    d_x = np.empty((csr.n_cols, F), dtype=np.float32)
+    d_w = np.empty(csr.n_edges, dtype=np.float32) if need_weight_grad else None
+    rc = lib().oracle_rspmm_backward(_p(csr.row_ptr), _p(csr.col), _p(csr.rel), _p(csr.w), _p(relation), _p(x),
+                                     _p(out), _p(grad), _p(d_rel), _p(d_x), _p(d_w), _i64(csr.n_rows),
+                                     _i64(csr.n_cols), _i64(csr.n_edges), _i64(csr.n_rel), _i64(F), SUM_OPS[sum],
+                                     MUL_OPS[mul], _i64(piece))
+    if rc:
+        raise RuntimeError("oracle_rspmm_backward failed: %d" % rc)
+    return (d_rel, d_x, d_w) if need_weight_grad else (d_rel, d_x)
+
+
+def rspmm_materialised(dst, src, rel, w, relation, x, n_rows, sum="add", mul="mul", dtype=np.float32):
+    """``ultra/layer.py:232-296`` without the boundary rows: O(E*F) messages then a scatter."""
+    relation = np.asarray(relation, dtype=dtype)
+    x = np.asarray(x, dtype=dtype)
+    dst = np.asarray(dst, dtype=np.int64)
+    w = np.ones(dst.shape[0], dtype=dtype) if w is None else np.asarray(w, dtype=dtype)
+    node_input = x[np.asarray(src, dtype=np.int64)]          # layer.py:249
+    edge_input = relation[np.asarray(rel, dtype=np.int64)]   # layer.py:250
+    message = edge_input + node_input if mul == "add" else edge_input * node_input  # :252-255
+    message = message * w[:, None]                            # :275
+    F = x.shape[1]
+    if sum == "add":
+        out = np.zeros((n_rows, F), dtype=dtype)
+        np.add.at(out, dst, message)                          # scatter_add :276
+    elif sum == "max":
+        out = np.full((n_rows, F), -np.inf, dtype=dtype)
+        np.maximum.at(out, dst, message)                      # scatter_max :280
+    elif sum == "min":
+        out = np.full((n_rows, F), np.inf, dtype=dtype)
+        np.minimum.at(out, dst, message)                      # scatter_min :285
+    else:
+        raise ValueError(sum)
+    return out
+
+
+def rspmm_python(dst, src, rel, w, relation, x, n_rows, sum="add", mul="mul"):
+    """Plain loops in Python floats (fp64); tiny graphs only."""
+    F = len(x[0])
+    ident = {"add": 0.0, "min": float("inf"), "max": float("-inf")}[sum]
+    out = [[ident] * F for _ in range(n_rows)]
+    for k in range(len(dst)):
+        wk = 1.0 if w is None else float(w[k])
+        for f in range(F):
+            r, xv = float(relation[rel[k]][f]), float(x[src[k]][f])
+            y = wk * (r * xv if mul == "mul" else r + xv)
+            cur = out[dst[k]][f]
+            out[dst[k]][f] = cur + y if sum == "add" else (min(cur, y) if sum == "min" else max(cur, y))
+    return out
+
+
+def filtered_rank(pred, mask, target):
+    """``ultra/task.py:307-315``: ``sum((pos_pred <= pred) & mask, -1) + 1``."""
+    pred = np.ascontiguousarray(pred, dtype=np.float32)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.int64)
+    nq, nc = pred.shape
+    rank = np.empty(nq, dtype=np.int64)
+    rc = lib().oracle_filtered_rank(_p(pred), _p(mask), _p(target), _p(rank), _i64(nq), _i64(nc))
+    if rc:
+        raise RuntimeError("oracle_filtered_rank failed")
+    return rank

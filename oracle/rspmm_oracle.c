@@ -1,0 +1,265 @@
+/*
+ * oracle/rspmm_oracle.c  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the relational sparse-matrix product ("rspmm") that the
+ * reference calls as torchdrug.layers.functional.generalized_rspmm from
+ *   /root/reference/ultra/layer.py:134-167   (relation-graph stack)
+ *   /root/reference/ultra/layer.py:336-369   (entity stack)
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this file's shared object.  The shipped path (ultra_torchdrug_amd/)
+ * never does.
+ *
+ * PARITY UNPINNED.  The arithmetic lives in torchdrug (requirements.txt:3,
+ * "torchdrug>=0.2.1", un-vendored; not installed, no network), the reference
+ * has no tests, golden vectors or fixtures, and its modules cannot be imported
+ * here (ordinary ModuleNotFoundError: torchdrug, torch_scatter).  What this
+ * file follows instead:
+ *   (1) the reference's own materialised definition of the same operator,
+ *       ultra/layer.py:232-296 (twin :52-109): message = relation[rel] (+|*)
+ *       input[node_in] (:249-255), update = scatter_{add,max,min}(message *
+ *       edge_weight, node_out, dim_size=num_node) (:275-285);
+ *   (2) the published torchdrug algorithm (rspmm.cpp / rspmm.cu, v0.2.x), from
+ *       memory: coalesce() sorts the COO (row, col, rel) and merges duplicate
+ *       triples by summing their values; per output row the edges are visited
+ *       in that sorted order and accumulated sequentially,
+ *           x = BinaryOp(relation[rel], input[col]);  y = value * x;
+ *           out = NaryOp(out, y);
+ *       with out starting at 0 (add), +inf (min), -inf (max); the backward
+ *       forms grad * dOut/dy * dy/dx * dx/d{input,relation} per edge, where
+ *       dOut/dy is 1 for add and (out == y) for min/max.
+ * Decisions taken because torchdrug cannot be consulted are marked DECISION.
+ *
+ * Summation order.  `piece == 0` is the reference order: strictly sequential
+ * per target row.  `piece > 0` is the documented order of the HIP kernels: a
+ * target row whose sorted contribution list is longer than `piece` is summed
+ * in consecutive pieces of `piece` contributions, each piece sequentially
+ * from the identity, and the piece sums are then added in piece order.  Rows
+ * with at most `piece` contributions are identical in both modes.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { ORACLE_SUM_ADD = 0, ORACLE_SUM_MIN = 1, ORACLE_SUM_MAX = 2 };
+enum { ORACLE_MUL_MUL = 0, ORACLE_MUL_ADD = 1 };
+
+/* BinaryOp::forward -- ultra/layer.py:252-255 (transe: "+", distmult: "*") */
+static inline float binary_fwd(int mul_op, float r, float x) {
+    return mul_op == ORACLE_MUL_MUL ? r * x : r + x;
+}
+/* d(binary)/d(input) and d(binary)/d(relation) */
+static inline float binary_bwd_in(int mul_op, float r, float x) {
+    (void)x;
+    return mul_op == ORACLE_MUL_MUL ? r : 1.0f;
+}
+static inline float binary_bwd_rel(int mul_op, float r, float x) {
+    (void)r;
+    return mul_op == ORACLE_MUL_MUL ? x : 1.0f;
+}
+/* NaryOp::forward.  DECISION: min/max are "keep the accumulator unless the
+ * new value is strictly smaller/larger" (a NaN message never replaces it). */
+static inline float nary_fwd(int sum_op, float acc, float y) {
+    if (sum_op == ORACLE_SUM_ADD) return acc + y;
+    if (sum_op == ORACLE_SUM_MIN) return (y < acc) ? y : acc;
+    return (y > acc) ? y : acc;
+}
+static inline float nary_identity(int sum_op) {
+    if (sum_op == ORACLE_SUM_ADD) return 0.0f;
+    if (sum_op == ORACLE_SUM_MIN) return INFINITY; /* DECISION: empty row -> +inf */
+    return -INFINITY;                               /* DECISION: empty row -> -inf */
+}
+
+int oracle_abi_version(void) { return 1; }
+
+/*
+ * Forward.  row_ptr[N_rows+1], col/rel/w[E] are the coalesced CSR of the
+ * (N_dst, N_src, R) adjacency the reference hands over at layer.py:127,328
+ * (rows = destination node).  w may be NULL (all ones).
+ * relation[R*F], x[N_cols*F], out[N_rows*F] row-major, fp32.
+ */
+int oracle_rspmm_forward(const int32_t *row_ptr, const int32_t *col, const int32_t *rel, const float *w,
+                         const float *relation, const float *x, float *out, int64_t n_rows, int64_t n_edges,
+                         int64_t n_rel, int64_t F, int sum_op, int mul_op, int64_t piece) {
+    (void)n_edges;
+    (void)n_rel;
+    if (sum_op < 0 || sum_op > 2 || mul_op < 0 || mul_op > 1) return 1;
+    const float ident = nary_identity(sum_op);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t v = 0; v < n_rows; ++v) {
+        float *o = out + v * F;
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        const int split = (piece > 0 && (e - b) > piece);
+        for (int64_t f = 0; f < F; ++f) o[f] = ident;
+        if (!split) {
+            for (int64_t k = b; k < e; ++k) {
+                const float *xr = x + (int64_t)col[k] * F;
+                const float *rr = relation + (int64_t)rel[k] * F;
+                const float wk = w ? w[k] : 1.0f;
+                for (int64_t f = 0; f < F; ++f) {
+                    float m = binary_fwd(mul_op, rr[f], xr[f]);
+                    float y = wk * m;
+                    o[f] = nary_fwd(sum_op, o[f], y);
+                }
+            }
+        } else {
+            float *pacc = (float *)malloc(sizeof(float) * (size_t)F);
+            for (int64_t p0 = b; p0 < e; p0 += piece) {
+                const int64_t p1 = (p0 + piece < e) ? p0 + piece : e;
+                for (int64_t f = 0; f < F; ++f) pacc[f] = ident;
+                for (int64_t k = p0; k < p1; ++k) {
+                    const float *xr = x + (int64_t)col[k] * F;
+                    const float *rr = relation + (int64_t)rel[k] * F;
+                    const float wk = w ? w[k] : 1.0f;
+                    for (int64_t f = 0; f < F; ++f) {
+                        float m = binary_fwd(mul_op, rr[f], xr[f]);
+                        float y = wk * m;
+                        pacc[f] = nary_fwd(sum_op, pacc[f], y);
+                    }
+                }
+                for (int64_t f = 0; f < F; ++f) o[f] = nary_fwd(sum_op, o[f], pacc[f]);
+            }
+            free(pacc);
+        }
+    }
+    return 0;
+}
+
+/*
+ * Generic "sorted contribution list" reducer used by the backward:
+ * target rows t = 0..n_targets-1 own the contributions order[tptr[t]..tptr[t+1])
+ * (indices into the CSR edge arrays), visited in that order.
+ *   which == 0: d_x[target = col]      contribution = ((g * dmask) * w) * d(binary)/d(input)
+ *   which == 1: d_relation[target=rel] contribution = ((g * dmask) * w) * d(binary)/d(relation)
+ * DECISION (product order): as torchdrug multiplies grad * dout_dy * dy_dx * dx_dz.
+ * DECISION (min/max): every edge whose y equals out receives the gradient.
+ */
+static void reduce_targets(int which, const int64_t *tptr, const int64_t *order, int64_t n_targets,
+                           const int32_t *row_of, const int32_t *col, const int32_t *rel, const float *w,
+                           const float *relation, const float *x, const float *out, const float *g, float *dst,
+                           int64_t F, int sum_op, int mul_op, int64_t piece) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t t = 0; t < n_targets; ++t) {
+        float *d = dst + t * F;
+        const int64_t b = tptr[t], e = tptr[t + 1];
+        const int split = (piece > 0 && (e - b) > piece);
+        const int64_t step = split ? piece : (e - b > 0 ? e - b : 1);
+        float *pacc = (float *)malloc(sizeof(float) * (size_t)F);
+        for (int64_t f = 0; f < F; ++f) d[f] = 0.0f;
+        for (int64_t p0 = b; p0 < e; p0 += step) {
+            const int64_t p1 = (p0 + step < e) ? p0 + step : e;
+            for (int64_t f = 0; f < F; ++f) pacc[f] = 0.0f;
+            for (int64_t q = p0; q < p1; ++q) {
+                const int64_t k = order[q];
+                const int64_t v = row_of[k];
+                const float *xr = x + (int64_t)col[k] * F;
+                const float *rr = relation + (int64_t)rel[k] * F;
+                const float *gr = g + v * F;
+                const float *orow = out + v * F;
+                const float wk = w ? w[k] : 1.0f;
+                for (int64_t f = 0; f < F; ++f) {
+                    float dmask = 1.0f;
+                    if (sum_op != ORACLE_SUM_ADD) {
+                        float y = wk * binary_fwd(mul_op, rr[f], xr[f]);
+                        dmask = (orow[f] == y) ? 1.0f : 0.0f;
+                    }
+                    float dz = which == 0 ? binary_bwd_in(mul_op, rr[f], xr[f]) : binary_bwd_rel(mul_op, rr[f], xr[f]);
+                    float c = ((gr[f] * dmask) * wk) * dz;
+                    pacc[f] = pacc[f] + c;
+                }
+            }
+            if (!split)
+                for (int64_t f = 0; f < F; ++f) d[f] = pacc[f];
+            else
+                for (int64_t f = 0; f < F; ++f) d[f] = d[f] + pacc[f];
+        }
+        free(pacc);
+    }
+}
+
+/* stable counting sort of edge ids by key (keeps CSR order inside a key) */
+static int bucket_order(const int32_t *key, int64_t n_edges, int64_t n_keys, int64_t **ptr_out, int64_t **order_out) {
+    int64_t *ptr = (int64_t *)calloc((size_t)n_keys + 1, sizeof(int64_t));
+    int64_t *order = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_edges > 0 ? n_edges : 1));
+    int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_keys + 1));
+    if (!ptr || !order || !fill) return 1;
+    for (int64_t k = 0; k < n_edges; ++k) ptr[key[k] + 1]++;
+    for (int64_t i = 0; i < n_keys; ++i) ptr[i + 1] += ptr[i];
+    memcpy(fill, ptr, sizeof(int64_t) * (size_t)(n_keys + 1));
+    for (int64_t k = 0; k < n_edges; ++k) order[fill[key[k]]++] = k;
+    free(fill);
+    *ptr_out = ptr;
+    *order_out = order;
+    return 0;
+}
+
+/*
+ * Backward.  Same CSR as the forward plus out (forward result, needed for
+ * min/max) and g = dL/d(out).  Produces d_relation[R*F], d_x[N_cols*F] and,
+ * when d_w != NULL, d_w[E] = sum_f g * dmask * binary(rel, x)   (the value
+ * gradient torchdrug returns when the sparse tensor requires grad).
+ * A sequential CSR sweep that does `+=` into d_x / d_relation visits the
+ * contributions of one target in CSR order; bucketing the edges by target with
+ * a stable sort reproduces exactly that order, and lets `piece` be applied.
+ */
+int oracle_rspmm_backward(const int32_t *row_ptr, const int32_t *col, const int32_t *rel, const float *w,
+                          const float *relation, const float *x, const float *out, const float *g, float *d_relation,
+                          float *d_x, float *d_w, int64_t n_rows, int64_t n_cols, int64_t n_edges, int64_t n_rel,
+                          int64_t F, int sum_op, int mul_op, int64_t piece) {
+    if (sum_op < 0 || sum_op > 2 || mul_op < 0 || mul_op > 1) return 1;
+    int32_t *row_of = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_edges > 0 ? n_edges : 1));
+    if (!row_of) return 2;
+    for (int64_t v = 0; v < n_rows; ++v)
+        for (int64_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) row_of[k] = (int32_t)v;
+
+    int64_t *ptr = NULL, *order = NULL;
+    if (bucket_order(col, n_edges, n_cols, &ptr, &order)) return 2;
+    reduce_targets(0, ptr, order, n_cols, row_of, col, rel, w, relation, x, out, g, d_x, F, sum_op, mul_op, piece);
+    free(ptr);
+    free(order);
+    if (bucket_order(rel, n_edges, n_rel, &ptr, &order)) return 2;
+    reduce_targets(1, ptr, order, n_rel, row_of, col, rel, w, relation, x, out, g, d_relation, F, sum_op, mul_op,
+                   piece);
+    free(ptr);
+    free(order);
+
+    if (d_w) {
+#pragma omp parallel for schedule(static)
+        for (int64_t k = 0; k < n_edges; ++k) {
+            const int64_t v = row_of[k];
+            const float *xr = x + (int64_t)col[k] * F;
+            const float *rr = relation + (int64_t)rel[k] * F;
+            const float wk = w ? w[k] : 1.0f;
+            float acc = 0.0f;
+            for (int64_t f = 0; f < F; ++f) {
+                float m = binary_fwd(mul_op, rr[f], xr[f]);
+                float dmask = 1.0f;
+                if (sum_op != ORACLE_SUM_ADD) dmask = (out[v * F + f] == wk * m) ? 1.0f : 0.0f;
+                acc = acc + (g[v * F + f] * dmask) * m;
+            }
+            d_w[k] = acc;
+        }
+    }
+    free(row_of);
+    return 0;
+}
+
+/*
+ * Filtered ranking, ultra/task.py:307-315:
+ *   ranking = sum((pos_pred <= pred) & mask, dim=-1) + 1
+ * pred[n_query*n_cand] fp32, mask[n_query*n_cand] u8, target[n_query] -> rank[n_query] int64.
+ */
+int oracle_filtered_rank(const float *pred, const uint8_t *mask, const int64_t *target, int64_t *rank,
+                         int64_t n_query, int64_t n_cand) {
+    for (int64_t q = 0; q < n_query; ++q) {
+        const float *p = pred + q * n_cand;
+        const uint8_t *m = mask + q * n_cand;
+        const float pos = p[target[q]];
+        int64_t r = 0;
+        for (int64_t c = 0; c < n_cand; ++c) r += (pos <= p[c]) && m[c];
+        rank[q] = r + 1;
+    }
+    return 0;
+}

@@ -1,0 +1,219 @@
+"""GPU parity: libultra_rspmm.so (through the C ABI / ctypes) against the CPU oracle on the same seeded inputs.
+
+Bars (fp32): with the oracle in the kernels' documented summation order (`piece=PIECE_LEN`) every element must
+be IDENTICAL; against the strictly sequential reference order (`piece=0`) rows that were not split are identical
+and split rows agree to rtol=1e-5 / atol=1e-5 (only the order of fp32 additions differs).
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from graphs import kg_graph, random_graph
+
+pytestmark = pytest.mark.gpu
+
+SUMS = ["add", "min", "max"]
+MULS = ["mul", "add"]
+RTOL, ATOL = 1e-5, 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _relcsr(g, n_dst, n_src, n_rel):
+    from ultra_torchdrug_amd import RelCSR
+    dev = _dev()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), None if g["w"] is None else t(g["w"]), n_dst, n_src, n_rel)
+
+
+def _inputs(seed, n_src, n_rel, F):
+    rng = np.random.default_rng(seed + 1000)
+    return (rng.standard_normal((n_rel, F)).astype(np.float32), rng.standard_normal((n_src, F)).astype(np.float32))
+
+
+def _same(a, b):
+    """Bitwise-equal as numbers (+0 == -0; inf == inf)."""
+    return np.array_equal(a, b)
+
+
+CASES = {
+    # name: (graph kwargs, n_node, n_rel, F)
+    "small_uniform": (dict(n_edge=3000, skew=False), 200, 7, 64),
+    "small_weights": (dict(n_edge=3000, skew=False, weights=True), 200, 7, 128),
+    "skewed_hub": (dict(n_edge=20000, skew=True, hub_row=5, hub_edges=3000), 500, 30, 192),
+    "isolated_and_ragged_F": (dict(n_edge=2000, isolated=150), 400, 5, 100),
+    "narrow_F": (dict(n_edge=500, weights=True), 64, 3, 1),
+    "many_relations_no_lds": (dict(n_edge=6000, skew=True), 300, 700, 64),
+    "rel_graph_like": (dict(n_edge=40000, skew=False, unique=True), 120, 4, 1024),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("sum", SUMS)
+@pytest.mark.parametrize("mul", MULS)
+def test_forward_matches_oracle(oracle, case, sum, mul):
+    from ultra_torchdrug_amd import functional as UF
+    from ultra_torchdrug_amd.relcsr import PIECE_LEN
+    kw, n, r, F = CASES[case]
+    g = random_graph(seed=zlib.crc32(case.encode()) % 1000, n_node=n, n_rel=r, **kw)
+    relation, x = _inputs(1, n, r, F)
+    csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    want_kernel_order = oracle.rspmm_forward(csr_o, relation, x, sum, mul, piece=PIECE_LEN)
+    want_sequential = oracle.rspmm_forward(csr_o, relation, x, sum, mul, piece=0)
+
+    csr = _relcsr(g, n, n, r)
+    assert csr.n_edges == csr_o.n_edges
+    dev = _dev()
+    got = UF.generalized_rspmm(csr, torch.from_numpy(relation).to(dev), torch.from_numpy(x).to(dev), sum=sum, mul=mul)
+    got = got.cpu().numpy()
+    assert _same(got, want_kernel_order), "HIP result differs from the oracle in the kernels' summation order"
+    finite = np.isfinite(want_sequential)
+    assert np.array_equal(np.isfinite(got), finite)
+    np.testing.assert_allclose(got[finite], want_sequential[finite], rtol=RTOL, atol=ATOL)
+    # rows that were not split must be identical to the sequential reference order
+    deg = np.diff(csr_o.row_ptr)
+    short = deg <= PIECE_LEN
+    assert _same(got[short], want_sequential[short])
+
+
+@pytest.mark.parametrize("case", ["small_uniform", "small_weights", "skewed_hub", "isolated_and_ragged_F",
+                                  "many_relations_no_lds"])
+@pytest.mark.parametrize("sum", SUMS)
+@pytest.mark.parametrize("mul", MULS)
+def test_backward_matches_oracle(oracle, case, sum, mul):
+    from ultra_torchdrug_amd import functional as UF
+    from ultra_torchdrug_amd.relcsr import PIECE_LEN
+    kw, n, r, F = CASES[case]
+    kw = dict(kw, unique=True)   # min/max ties are only well defined on coalesced inputs; weights stay as given
+    g = random_graph(seed=zlib.crc32(case.encode()) % 1000 + 7, n_node=n, n_rel=r, **kw)
+    relation, x = _inputs(2, n, r, F)
+    rng = np.random.default_rng(5)
+    grad = rng.standard_normal((n, F)).astype(np.float32)
+    csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    out_o = oracle.rspmm_forward(csr_o, relation, x, sum, mul, piece=PIECE_LEN)
+    d_rel_k, d_x_k = oracle.rspmm_backward(csr_o, relation, x, out_o, grad, sum, mul, piece=PIECE_LEN)
+    d_rel_s, d_x_s = oracle.rspmm_backward(csr_o, relation, x, out_o, grad, sum, mul, piece=0)
+
+    dev = _dev()
+    csr = _relcsr(g, n, n, r)
+    rel_t = torch.from_numpy(relation).to(dev).requires_grad_()
+    x_t = torch.from_numpy(x).to(dev).requires_grad_()
+    out = UF.generalized_rspmm(csr, rel_t, x_t, sum=sum, mul=mul)
+    assert _same(out.detach().cpu().numpy(), out_o)
+    out.backward(torch.from_numpy(grad).to(dev))
+    d_rel, d_x = rel_t.grad.cpu().numpy(), x_t.grad.cpu().numpy()
+    assert _same(d_x, d_x_k), "d_input differs from the oracle in kernel order"
+    assert _same(d_rel, d_rel_k), "d_relation differs from the oracle in kernel order"
+    np.testing.assert_allclose(d_x, d_x_s, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(d_rel, d_rel_s, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("sum", SUMS)
+def test_weight_gradient(oracle, sum):
+    """d(values) for a sparse tensor that requires grad (torchdrug returns it; unused by the shipped configs)."""
+    from ultra_torchdrug_amd import functional as UF
+    n, r, F = 150, 6, 96
+    g = random_graph(seed=3, n_node=n, n_edge=2500, n_rel=r, unique=True, weights=True)
+    relation, x = _inputs(3, n, r, F)
+    grad = np.random.default_rng(9).standard_normal((n, F)).astype(np.float32)
+    csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    out_o = oracle.rspmm_forward(csr_o, relation, x, sum, "mul", piece=0)
+    _, _, d_w_o = oracle.rspmm_backward(csr_o, relation, x, out_o, grad, sum, "mul", need_weight_grad=True)
+    dev = _dev()
+    idx = torch.from_numpy(np.stack([g["dst"], g["src"], g["rel"]])).to(dev)
+    val = torch.from_numpy(g["w"]).to(dev).requires_grad_()
+    sparse = torch.sparse_coo_tensor(idx, val, (n, n, r))
+    out = UF.generalized_rspmm(sparse, torch.from_numpy(relation).to(dev), torch.from_numpy(x).to(dev), sum=sum)
+    out.backward(torch.from_numpy(grad).to(dev))
+    # map oracle (coalesced order) back to input order
+    key_o = (csr_o.row.astype(np.int64) * n + csr_o.col) * r + csr_o.rel
+    key_in = (g["dst"] * n + g["src"]) * r + g["rel"]
+    pos = np.searchsorted(key_o, key_in)
+    np.testing.assert_allclose(val.grad.cpu().numpy(), d_w_o[pos], rtol=1e-4, atol=1e-4)
+
+
+def test_fused_boundary_epilogue(oracle):
+    """add_rows fuses `update + boundary` / `max(update, boundary)` (layer.py:156,162,358,364)."""
+    from ultra_torchdrug_amd import functional as UF
+    n, r, F = 300, 9, 128
+    g = random_graph(seed=11, n_node=n, n_edge=9000, n_rel=r, skew=True, hub_row=2, hub_edges=1000, isolated=20)
+    relation, x = _inputs(4, n, r, F)
+    boundary = np.random.default_rng(2).standard_normal((n, F)).astype(np.float32)
+    dev = _dev()
+    csr = _relcsr(g, n, n, r)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    for sum in SUMS:
+        plain = UF.rspmm_forward(csr, t(relation), t(x), sum, "mul")
+        fused = UF.rspmm_forward(csr, t(relation), t(x), sum, "mul", add_rows=t(boundary))
+        b = t(boundary)
+        want = plain + b if sum == "add" else (torch.maximum(plain, b) if sum == "max" else torch.minimum(plain, b))
+        assert torch.equal(fused, want)
+
+
+def test_sparse_tensor_entry_and_errors():
+    """Same call shape as the reference (layer.py:357): positional (adjacency, relation_input, input)."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = _dev()
+    n, r, F = 50, 3, 64
+    g = random_graph(seed=1, n_node=n, n_edge=400, n_rel=r)
+    idx = torch.from_numpy(np.stack([g["src"], g["dst"], g["rel"]])).to(dev)       # graph.adjacency: (in, out, rel)
+    adjacency = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1], device=dev), (n, n, r)).transpose(0, 1)
+    relation = torch.randn(r, F, device=dev)
+    x = torch.randn(n, F, device=dev)
+    out = UF.generalized_rspmm(adjacency, relation, x, sum="add", mul="mul")
+    dense = torch.zeros(n, F, device=dev)
+    msg = relation[idx[2]] * x[idx[0]]
+    dense.index_add_(0, idx[1], msg)
+    torch.testing.assert_close(out, dense, rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError):
+        UF.generalized_rspmm(adjacency, relation, x, sum="mean")
+    with pytest.raises(ValueError):
+        UF.generalized_rspmm(adjacency, relation, x, mul="rotate")
+    with pytest.raises(RuntimeError):
+        UF.generalized_rspmm(adjacency, relation, x[:-1])
+    with pytest.raises(RuntimeError):
+        UF.generalized_rspmm(adjacency.cpu(), relation.cpu(), x.cpu())      # no CPU fallback
+    v = UF.generalized_rspmm(adjacency, relation[:, 0].contiguous(), x[:, 0].contiguous())   # 1-D input
+    torch.testing.assert_close(v, dense[:, 0], rtol=1e-4, atol=1e-4)
+
+
+def test_empty_graph_and_empty_rows():
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    dev = _dev()
+    e = torch.zeros(0, dtype=torch.long, device=dev)
+    csr = RelCSR(e, e, e, None, 130, 130, 4)
+    relation = torch.randn(4, 64, device=dev)
+    x = torch.randn(130, 64, device=dev)
+    assert torch.equal(UF.generalized_rspmm(csr, relation, x, sum="add"), torch.zeros(130, 64, device=dev))
+    assert torch.isinf(UF.generalized_rspmm(csr, relation, x, sum="max")).all()
+    assert (UF.generalized_rspmm(csr, relation, x, sum="min") == float("inf")).all()
+
+
+def test_fb15k237_shape_properties(oracle):
+    """BASELINE-size graph (S-fb15k237, B=16): linearity in input and a CPU spot check on a row subset."""
+    from ultra_torchdrug_amd import functional as UF
+    n, base_r, triples, F = 14541, 237, 272115, 1024
+    g = kg_graph(1024, n, triples, base_r)
+    r = 2 * base_r
+    dev = _dev()
+    csr = _relcsr(g, n, n, r)
+    gen = torch.Generator(device="cpu").manual_seed(1024)
+    relation = torch.randn(r, F, generator=gen).to(dev)
+    x1 = torch.randn(n, F, generator=gen).to(dev)
+    x2 = torch.randn(n, F, generator=gen).to(dev)
+    o1 = UF.generalized_rspmm(csr, relation, x1)
+    o2 = UF.generalized_rspmm(csr, relation, x2)
+    o12 = UF.generalized_rspmm(csr, relation, x1 + x2)
+    scale = o12.abs().max().item()
+    assert (o12 - (o1 + o2)).abs().max().item() <= 2e-5 * scale + 1e-3
+    assert torch.equal(UF.generalized_rspmm(csr, relation, x1), o1)          # deterministic: run-to-run identical
+    # oracle on the first 64 columns (one tile) of the whole graph
+    csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], None, n, n, r)
+    from ultra_torchdrug_amd.relcsr import PIECE_LEN
+    want = oracle.rspmm_forward(csr_o, relation[:, :64].cpu().numpy(), x1[:, :64].cpu().numpy(), piece=PIECE_LEN)
+    assert np.array_equal(o1[:, :64].cpu().numpy(), want)

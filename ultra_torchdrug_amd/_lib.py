@@ -1,0 +1,110 @@
+"""ctypes binding of ``libultra_rspmm.so`` (C ABI: ``include/ultra_rspmm.h``).
+
+The shared object is the product: there is no Python, PyTorch or CPU fallback behind it.  If it is missing or
+cannot be loaded every operator of this package raises immediately.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libultra_rspmm.so")
+ABI_VERSION = 1
+
+SUM_OPS = {"add": 0, "min": 1, "max": 2}
+MUL_OPS = {"mul": 0, "add": 1}
+
+
+class UltraSegments(ctypes.Structure):
+    """``struct ultra_segments`` of include/ultra_rspmm.h (device pointers as integers)."""
+    _fields_ = [
+        ("n_rows", ctypes.c_int64),
+        ("n_edges", ctypes.c_int64),
+        ("row", ctypes.c_void_p),
+        ("node_a", ctypes.c_void_p),
+        ("node_b", ctypes.c_void_p),
+        ("rel", ctypes.c_void_p),
+        ("weight", ctypes.c_void_p),
+        ("n_chunks", ctypes.c_int64),
+        ("chunks", ctypes.c_void_p),
+        ("n_long_rows", ctypes.c_int64),
+        ("long_rows", ctypes.c_void_p),
+        ("n_pieces", ctypes.c_int64),
+        ("piece_len", ctypes.c_int64),
+    ]
+
+
+EXPORTS = (
+    "ultra_rspmm_abi_version",
+    "ultra_rspmm_status_string",
+    "ultra_rspmm_last_hip_error",
+    "ultra_rspmm_device_info",
+    "ultra_rspmm_workspace_bytes",
+    "ultra_rspmm_forward_f32",
+    "ultra_rspmm_backward_f32",
+    "ultra_rspmm_backward_weight_f32",
+)
+
+_lib = None
+
+
+class UltraLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once; raise :class:`UltraLibraryError` if it is absent (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UltraLibraryError(
+            "%s not found: build it with `make -C ultra_torchdrug_amd/csrc` (hipcc --offload-arch=gfx950) or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU/PyTorch fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as err:  # missing libamdhip64 etc.
+        raise UltraLibraryError("cannot load %s: %s" % (LIB_PATH, err)) from err
+    missing = [name for name in EXPORTS if not hasattr(lib, name)]
+    if missing:
+        raise UltraLibraryError("%s lacks symbols %s" % (LIB_PATH, missing))
+
+    vp, i64, i32, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+    seg = ctypes.POINTER(UltraSegments)
+    lib.ultra_rspmm_abi_version.restype = i32
+    lib.ultra_rspmm_abi_version.argtypes = []
+    lib.ultra_rspmm_status_string.restype = ctypes.c_char_p
+    lib.ultra_rspmm_status_string.argtypes = [i32]
+    lib.ultra_rspmm_last_hip_error.restype = i32
+    lib.ultra_rspmm_last_hip_error.argtypes = []
+    lib.ultra_rspmm_device_info.restype = i32
+    lib.ultra_rspmm_device_info.argtypes = [i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.c_char_p, sz]
+    lib.ultra_rspmm_workspace_bytes.restype = sz
+    lib.ultra_rspmm_workspace_bytes.argtypes = [seg, i64]
+    lib.ultra_rspmm_forward_f32.restype = i32
+    lib.ultra_rspmm_forward_f32.argtypes = [seg, vp, vp, vp, vp, vp, sz, i64, i64, i32, i32, vp]
+    lib.ultra_rspmm_backward_f32.restype = i32
+    lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i32, i32, vp]
+    lib.ultra_rspmm_backward_weight_f32.restype = i32
+    lib.ultra_rspmm_backward_weight_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
+    if lib.ultra_rspmm_abi_version() != ABI_VERSION:
+        raise UltraLibraryError("ABI mismatch: library %d, binding %d" % (lib.ultra_rspmm_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status):
+    """Turn a non-zero ``ultra_status`` into a RuntimeError (TORCH_CHECK-like behaviour of the reference op)."""
+    if status != 0:
+        lib = load()
+        msg = lib.ultra_rspmm_status_string(status).decode()
+        if status == 5:
+            msg += " [hipError_t=%d]" % lib.ultra_rspmm_last_hip_error()
+        raise RuntimeError("libultra_rspmm: %s" % msg)
+
+
+def device_info(device=0):
+    lib = load()
+    n_cu, lds = ctypes.c_int(0), ctypes.c_int(0)
+    arch = ctypes.create_string_buffer(64)
+    check(lib.ultra_rspmm_device_info(int(device), ctypes.byref(n_cu), ctypes.byref(lds), arch, 64))
+    return {"n_cu": n_cu.value, "lds_bytes": lds.value, "arch": arch.value.decode()}

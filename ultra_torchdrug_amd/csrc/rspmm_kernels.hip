@@ -1,0 +1,601 @@
+// ultra_torchdrug_amd/csrc/rspmm_kernels.hip -- gfx950 (MI355X) kernels + C ABI of libultra_rspmm.so
+//
+// Replaces the native operator behind torchdrug.layers.functional.generalized_rspmm, which the reference
+// calls at /root/reference/ultra/layer.py:134-167 and :336-369 (see include/ultra_rspmm.h).
+//
+// Design (DESIGN.md has the numbers):
+//  * one lane = one fp32 column, one wave = one 64-column tile of a row; F is cut into ceil(F/64) tiles.
+//    A tile of one source row is a 256-B contiguous segment, so every gather is one fully coalesced
+//    global_load_dword per wave and each lane accumulates ITS column strictly in sorted-edge order
+//    (that is what makes unsplit rows bit-identical to the sequential CPU oracle).
+//  * the relation table of the tile (n_rel x 64 fp32) is staged once per workgroup in LDS, so the
+//    per-edge relation operand costs one conflict-free ds_read_b32 and no L2 traffic.
+//  * persistent grid, XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch, speed only, never
+//    correctness), so label = blockIdx % 8 owns whole column tiles: the N x 256 B slice of `input` that a
+//    tile touches (3.7 MB for FB15k237) then lives in ONE XCD's 4 MB L2 while that tile is processed.
+//  * per-wavefront segmented reduction over a precomputed chunk schedule (ultra_segments): a chunk is a
+//    run of whole rows or one piece of a long row; edge metadata is wave-uniform and comes in through
+//    scalar loads; UNROLL gathers are in flight per wave.  Long-row pieces go to a workspace and are added
+//    in piece order by fixup_kernel: deterministic, no atomics.
+//  * compiled with -ffp-contract=off: message = w * (rel (*|+) x) is rounded before it is accumulated,
+//    exactly as the oracle does.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "ultra_rspmm.h"
+
+namespace {
+
+constexpr int kTile = 64;            // columns per tile == wave width
+constexpr int kBlock = 1024;         // threads per workgroup (16 waves, 4 per SIMD)
+constexpr int kWaves = kBlock / 64;
+constexpr int kUnroll = 8;           // gathers in flight per wave
+constexpr int kXcd = 8;
+constexpr int kFixUnroll = 16;
+constexpr int kMaxLdsBytes = 156 * 1024;   // leave a little of the 160 KiB
+
+enum Kind { KIND_FWD = 0, KIND_DX = 1, KIND_DREL = 2 };
+
+struct KParams {
+    const int32_t *row;
+    const int32_t *node_a;
+    const int32_t *node_b;
+    const int32_t *rel;
+    const float *weight;
+    const int4 *chunks;
+    const float *relation;   // [n_rel, F]
+    const float *input;      // [n_src, F]
+    const float *output;     // [n_dst, F]   (min/max backward only)
+    const float *grad;       // [n_dst, F]   (backward only)
+    const float *add_rows;   // [n_rows, F]  (forward only, optional fused epilogue)
+    float *out;              // [n_rows, F]
+    float *partial;          // [n_pieces, F]
+    long long F;
+    int n_chunks;
+    int n_rel;
+    int n_tiles;
+    int split;
+    int n_slots;
+    int blocks_per_label;
+};
+
+struct FixParams {
+    const int32_t *long_rows;   // [n_long][3]
+    const float *partial;
+    const float *add_rows;
+    float *out;
+    long long F;
+    int n_long;
+    int n_tiles;
+};
+
+template <int SUM>
+__device__ __forceinline__ float identity() {
+    if constexpr (SUM == ULTRA_SUM_ADD) return 0.0f;
+    else if constexpr (SUM == ULTRA_SUM_MIN) return __builtin_inff();
+    else return -__builtin_inff();
+}
+
+template <int SUM>
+__device__ __forceinline__ float reduce(float acc, float y) {
+    if constexpr (SUM == ULTRA_SUM_ADD) return acc + y;
+    else if constexpr (SUM == ULTRA_SUM_MIN) return (y < acc) ? y : acc;
+    else return (y > acc) ? y : acc;
+}
+
+template <int MUL>
+__device__ __forceinline__ float binary(float r, float x) {
+    if constexpr (MUL == ULTRA_MUL_MUL) return r * x;
+    else return r + x;
+}
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// One chunk of the schedule, processed by one wave for one column tile.
+//   KIND_FWD : acc (SUM)= w * (relation[rel] MUL input[node_a])
+//   KIND_DX  : acc += ((grad[node_a] * dmask) * w) * d(MUL)/d(input)      rows = source nodes
+//   KIND_DREL: acc += ((grad[node_b] * dmask) * w) * d(MUL)/d(relation)   rows = relations
+// dmask = 1 for sum=add, (output == y) for min/max with y the forward message of that edge.
+template <int KIND, int SUM, int MUL, bool UNIT_W, bool REL_LDS>
+struct ChunkWalker {
+    static constexpr int RED = (KIND == KIND_FWD) ? SUM : ULTRA_SUM_ADD;
+    static constexpr bool MASKED = (KIND != KIND_FWD) && (SUM != ULTRA_SUM_ADD);
+    // the per-edge relation row is needed by the forward and by d_input (mask and/or d(mul)/d(input) = relation)
+    static constexpr bool NEED_REL_ID = (KIND == KIND_FWD) || (KIND == KIND_DX && (MASKED || MUL == ULTRA_MUL_MUL));
+
+    const KParams &p;
+    const long long F;
+    const long long col;    // this lane's column
+    const long long lcol;   // column used for loads: clamped into range so that loads never need a predicate
+    const bool active;      // col < F (stores only)
+    const float *lds_rel;
+    const int lane;
+    int cur;
+    float acc;
+    bool is_piece;
+
+    __device__ __forceinline__ float load_rel(int r) const {
+        if constexpr (REL_LDS) return lds_rel[r * kTile + lane];
+        else return p.relation[(long long)r * F + lcol];
+    }
+    __device__ __forceinline__ void store_row(int r, float v) const {
+        if (active) {
+            if constexpr (KIND == KIND_FWD) {
+                if (p.add_rows != nullptr) v = reduce<RED>(v, p.add_rows[(long long)r * F + col]);
+            }
+            p.out[(long long)r * F + col] = v;
+        }
+    }
+
+    // kUnroll consecutive edges starting at e0; FULL: all kUnroll exist, else only n of them.
+    template <bool FULL>
+    __device__ __forceinline__ void batch(const int e0, const int n) {
+        int ia[kUnroll], ib[kUnroll], ir[kUnroll], irow[kUnroll];
+        float wv[kUnroll];
+        float v0[kUnroll], v1[kUnroll], v2[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int e = FULL ? e0 + u : e0 + min(u, n - 1);   // tail slots re-load the last edge, never used
+            ia[u] = p.node_a[e];
+            irow[u] = p.row[e];
+            if constexpr (NEED_REL_ID) ir[u] = p.rel[e];
+            if constexpr (KIND == KIND_DREL) ib[u] = p.node_b[e];
+            if constexpr (!UNIT_W) wv[u] = p.weight[e];
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if constexpr (KIND == KIND_FWD) {
+                v0[u] = p.input[(long long)ia[u] * F + lcol];
+            } else if constexpr (KIND == KIND_DX) {
+                v0[u] = p.grad[(long long)ia[u] * F + lcol];
+                if constexpr (MASKED) {
+                    v1[u] = p.output[(long long)ia[u] * F + lcol];
+                    v2[u] = p.input[(long long)irow[u] * F + lcol];
+                }
+            } else {
+                v0[u] = p.grad[(long long)ib[u] * F + lcol];
+                if constexpr (MASKED || MUL == ULTRA_MUL_MUL) v2[u] = p.input[(long long)ia[u] * F + lcol];
+                if constexpr (MASKED) v1[u] = p.output[(long long)ib[u] * F + lcol];
+            }
+        }
+        // relation operands of the batch: issued together (LDS reads or, for tables too big for LDS, L2 loads)
+        float rv[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            rv[u] = 0.0f;
+            if constexpr (NEED_REL_ID) rv[u] = load_rel(ir[u]);
+            if constexpr (KIND == KIND_DREL && MASKED) rv[u] = p.relation[(long long)irow[u] * F + lcol];
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (FULL || u < n) {
+                if (!is_piece && irow[u] != cur) {
+                    store_row(cur, acc);
+                    for (int q = cur + 1; q < irow[u]; ++q) store_row(q, identity<RED>());
+                    cur = irow[u];
+                    acc = identity<RED>();
+                }
+                if constexpr (KIND == KIND_FWD) {
+                    float y = binary<MUL>(rv[u], v0[u]);
+                    if constexpr (!UNIT_W) y = wv[u] * y;
+                    acc = reduce<RED>(acc, y);
+                } else {
+                    float c = v0[u];   // grad[dst]
+                    if constexpr (MASKED) {
+                        float y = binary<MUL>(rv[u], v2[u]);   // forward message of this edge
+                        if constexpr (!UNIT_W) y = wv[u] * y;
+                        c = c * ((v1[u] == y) ? 1.0f : 0.0f);
+                    }
+                    if constexpr (!UNIT_W) c = c * wv[u];
+                    if constexpr (MUL == ULTRA_MUL_MUL) c = c * (KIND == KIND_DX ? rv[u] : v2[u]);
+                    acc = acc + c;
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void run(const int4 d) {
+        is_piece = d.w < 0;
+        cur = d.z;
+        acc = identity<RED>();
+        int e0 = d.x;
+        for (; e0 + kUnroll <= d.y; e0 += kUnroll) batch<true>(e0, kUnroll);
+        if (e0 < d.y) batch<false>(e0, d.y - e0);
+        if (is_piece) {
+            if (active) p.partial[(long long)(-d.w - 1) * F + col] = acc;
+        } else {
+            store_row(cur, acc);
+            for (int q = cur + 1; q < d.w; ++q) store_row(q, identity<RED>());
+        }
+    }
+};
+
+template <int KIND, int SUM, int MUL, bool UNIT_W, bool REL_LDS>
+__global__ __launch_bounds__(kBlock) void segment_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_rel[];
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform(threadIdx.x >> 6);
+    const int label = blockIdx.x % kXcd;          // blocks sharing an XCD (round-robin dispatch; speed only)
+    const int bl = blockIdx.x / kXcd;
+    const int widx = bl * kWaves + wave;
+    const int nw = p.blocks_per_label * kWaves;
+
+    for (int s = label; s < p.n_slots; s += kXcd) {
+        const int tile = s / p.split;
+        const int part = s - tile * p.split;
+        const long long col = (long long)tile * kTile + lane;
+        const bool active = col < p.F;
+        if constexpr (REL_LDS) {
+            const int total = p.n_rel * kTile;
+            for (int i = threadIdx.x; i < total; i += kBlock) {
+                const int r = i >> 6;
+                const long long c = (long long)tile * kTile + (i & 63);
+                lds_rel[i] = (c < p.F) ? p.relation[(long long)r * p.F + c] : 0.0f;
+            }
+            __syncthreads();
+        }
+        for (int k = part + p.split * widx; k < p.n_chunks; k += p.split * nw) {
+            const int4 d = p.chunks[uniform(k)];
+            ChunkWalker<KIND, SUM, MUL, UNIT_W, REL_LDS> walker{p, p.F, col, active ? col : p.F - 1, active, lds_rel, lane,
+                                                                0, 0.0f, false};
+            walker.run(d);
+        }
+        if constexpr (REL_LDS) __syncthreads();
+    }
+}
+
+// out[row] = epilogue( partial[first] (+) partial[first+1] (+) ... ) in piece order.
+template <int RED>
+__global__ __launch_bounds__(256) void fixup_kernel(const FixParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int total = p.n_long * p.n_tiles;
+    if (wave_global >= total) return;
+    const int lr = wave_global / p.n_tiles;
+    const int tile = wave_global - lr * p.n_tiles;
+    const long long col = (long long)tile * kTile + lane;
+    if (col >= p.F) return;
+    const int row = p.long_rows[lr * 3 + 0];
+    const int first = p.long_rows[lr * 3 + 1];
+    const int n = p.long_rows[lr * 3 + 2];
+    float acc = identity<RED>();
+    for (int k0 = 0; k0 < n; k0 += kFixUnroll) {
+        float v[kFixUnroll];
+#pragma unroll
+        for (int u = 0; u < kFixUnroll; ++u) {
+            const int k = min(k0 + u, n - 1);
+            v[u] = p.partial[(long long)(first + k) * p.F + col];
+        }
+#pragma unroll
+        for (int u = 0; u < kFixUnroll; ++u)
+            if (k0 + u < n) acc = reduce<RED>(acc, v[u]);
+    }
+    if (p.add_rows != nullptr) acc = reduce<RED>(acc, p.add_rows[(long long)row * p.F + col]);
+    p.out[(long long)row * p.F + col] = acc;
+}
+
+// d_weight[e] = sum_f (grad[dst,f] * dmask) * (relation[rel,f] MUL input[src,f]); one wave per edge.
+template <int SUM, int MUL, bool UNIT_W>
+__global__ __launch_bounds__(256) void weight_grad_kernel(const int32_t *row, const int32_t *src, const int32_t *rel,
+                                                          const float *weight, const float *relation,
+                                                          const float *input, const float *output, const float *grad,
+                                                          float *d_weight, long long F, long long n_edges) {
+    const int lane = threadIdx.x & 63;
+    const long long waves_total = ((long long)gridDim.x * blockDim.x) >> 6;
+    long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (; e < n_edges; e += waves_total) {
+        const int v = row[e], u = src[e], r = rel[e];
+        float wk = 1.0f;
+        if constexpr (!UNIT_W) wk = weight[e];
+        float acc = 0.0f;
+        for (long long f = lane; f < F; f += 64) {
+            const float m = binary<MUL>(relation[(long long)r * F + f], input[(long long)u * F + f]);
+            float g = grad[(long long)v * F + f];
+            if constexpr (SUM != ULTRA_SUM_ADD) {
+                float y = m;
+                if constexpr (!UNIT_W) y = wk * m;
+                g = g * ((output[(long long)v * F + f] == y) ? 1.0f : 0.0f);
+            }
+            acc = acc + g * m;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) d_weight[e] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+thread_local int g_last_hip_error = 0;
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) {                         \
+            g_last_hip_error = (int)_e;                 \
+            (void)hipGetLastError();                    \
+            return ULTRA_ERR_HIP;                       \
+        }                                               \
+    } while (0)
+
+struct DeviceInfo {
+    bool valid = false;
+    int n_cu = 0;
+    int lds_bytes = 0;
+    char arch[64] = {0};
+};
+DeviceInfo g_dev[16];
+
+int device_info(int device, DeviceInfo **out) {
+    if (device < 0 || device >= 16) return ULTRA_ERR_NO_DEVICE;
+    DeviceInfo &d = g_dev[device];
+    if (!d.valid) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        d.n_cu = prop.multiProcessorCount;
+        d.lds_bytes = (int)prop.maxSharedMemoryPerMultiProcessor;
+        std::strncpy(d.arch, prop.gcnArchName, sizeof(d.arch) - 1);
+        d.valid = true;
+    }
+    *out = &d;
+    return ULTRA_OK;
+}
+
+int gcd_int(int a, int b) {
+    while (b) {
+        int t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+template <int KIND, int SUM, int MUL, bool UNIT_W, bool REL_LDS>
+int launch_instance(const KParams &p, int grid, size_t lds, hipStream_t stream) {
+    auto kern = segment_kernel<KIND, SUM, MUL, UNIT_W, REL_LDS>;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (lds > 48 * 1024 && dev >= 0 && dev < 16 && !attr_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kMaxLdsBytes));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, p);
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
+template <int KIND, int SUM, int MUL>
+int launch_wl(const KParams &p, bool unit_w, bool rel_lds, int grid, size_t lds, hipStream_t stream) {
+    if constexpr (KIND == KIND_DREL) {   // rows are relations: no per-edge relation operand, no LDS table
+        if (unit_w) return launch_instance<KIND, SUM, MUL, true, false>(p, grid, 0, stream);
+        return launch_instance<KIND, SUM, MUL, false, false>(p, grid, 0, stream);
+    } else {
+        if (unit_w) {
+            if (rel_lds) return launch_instance<KIND, SUM, MUL, true, true>(p, grid, lds, stream);
+            return launch_instance<KIND, SUM, MUL, true, false>(p, grid, lds, stream);
+        }
+        if (rel_lds) return launch_instance<KIND, SUM, MUL, false, true>(p, grid, lds, stream);
+        return launch_instance<KIND, SUM, MUL, false, false>(p, grid, lds, stream);
+    }
+}
+
+template <int KIND>
+int launch_ops(const KParams &p, int sum_op, int mul_op, bool unit_w, bool rel_lds, int grid, size_t lds,
+               hipStream_t stream) {
+#define ULTRA_CASE(S, M)                                                    \
+    if (sum_op == S && mul_op == M) return launch_wl<KIND, S, M>(p, unit_w, rel_lds, grid, lds, stream);
+    ULTRA_CASE(ULTRA_SUM_ADD, ULTRA_MUL_MUL)
+    ULTRA_CASE(ULTRA_SUM_ADD, ULTRA_MUL_ADD)
+    ULTRA_CASE(ULTRA_SUM_MIN, ULTRA_MUL_MUL)
+    ULTRA_CASE(ULTRA_SUM_MIN, ULTRA_MUL_ADD)
+    ULTRA_CASE(ULTRA_SUM_MAX, ULTRA_MUL_MUL)
+    ULTRA_CASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
+#undef ULTRA_CASE
+    return ULTRA_ERR_BAD_OP;
+}
+
+int check_segments(const ultra_segments *s) {
+    if (s == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (s->n_rows < 0 || s->n_edges < 0 || s->n_chunks < 0 || s->n_pieces < 0 || s->n_long_rows < 0)
+        return ULTRA_ERR_BAD_SHAPE;
+    if (s->n_rows > 0x7fffffffLL || s->n_edges > 0x7fffffffLL || s->n_chunks > 0x7fffffffLL) return ULTRA_ERR_BAD_SHAPE;
+    if (s->n_edges > 0 && (s->row == nullptr || s->node_a == nullptr || s->rel == nullptr)) return ULTRA_ERR_NULL_POINTER;
+    if (s->n_chunks > 0 && s->chunks == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (s->n_long_rows > 0 && s->long_rows == nullptr) return ULTRA_ERR_NULL_POINTER;
+    return ULTRA_OK;
+}
+
+// Runs one plan: segment_kernel over the chunk schedule, then fixup_kernel over the split rows.
+template <int KIND>
+int run_plan(const ultra_segments *seg, KParams p, int64_t n_rel, int64_t F, int sum_op, int mul_op, bool wants_rel_lds,
+             void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    int rc = check_segments(seg);
+    if (rc) return rc;
+    if (F <= 0 || n_rel < 0 || n_rel > 0x7fffffffLL) return ULTRA_ERR_BAD_SHAPE;
+    if (sum_op < 0 || sum_op > 2 || mul_op < 0 || mul_op > 1) return ULTRA_ERR_BAD_OP;
+    const size_t need = ultra_rspmm_workspace_bytes(seg, F);
+    if (need > 0 && (workspace == nullptr || workspace_bytes < need)) return ULTRA_ERR_WORKSPACE;
+    if (seg->n_rows == 0) return ULTRA_OK;
+
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo *di = nullptr;
+    rc = device_info(dev, &di);
+    if (rc) return rc;
+
+    const int n_tiles = (int)((F + kTile - 1) / kTile);
+    const int split = kXcd / gcd_int(n_tiles, kXcd);
+    const size_t lds_need = (size_t)n_rel * kTile * sizeof(float);
+    const bool rel_lds = wants_rel_lds && n_rel > 0 && lds_need <= (size_t)kMaxLdsBytes;
+    const int blocks_per_label = (di->n_cu + kXcd - 1) / kXcd;
+
+    p.row = seg->row;
+    p.node_a = seg->node_a;
+    p.node_b = seg->node_b;
+    p.rel = seg->rel;
+    p.weight = seg->weight;
+    p.chunks = reinterpret_cast<const int4 *>(seg->chunks);
+    p.partial = static_cast<float *>(workspace);
+    p.F = F;
+    p.n_chunks = (int)seg->n_chunks;
+    p.n_rel = (int)n_rel;
+    p.n_tiles = n_tiles;
+    p.split = split;
+    p.n_slots = n_tiles * split;
+    p.blocks_per_label = blocks_per_label;
+
+    const int grid = blocks_per_label * kXcd;
+    rc = launch_ops<KIND>(p, sum_op, mul_op, seg->weight == nullptr, rel_lds, grid, rel_lds ? lds_need : 0, stream);
+    if (rc) return rc;
+
+    if (seg->n_long_rows > 0) {
+        FixParams fp;
+        fp.long_rows = seg->long_rows;
+        fp.partial = p.partial;
+        fp.add_rows = p.add_rows;
+        fp.out = p.out;
+        fp.F = F;
+        fp.n_long = (int)seg->n_long_rows;
+        fp.n_tiles = n_tiles;
+        const long long waves = (long long)fp.n_long * n_tiles;
+        const int fgrid = (int)((waves + 3) / 4);
+        const int red = (KIND == KIND_FWD) ? sum_op : ULTRA_SUM_ADD;
+        if (red == ULTRA_SUM_ADD) hipLaunchKernelGGL(fixup_kernel<ULTRA_SUM_ADD>, dim3(fgrid), dim3(256), 0, stream, fp);
+        else if (red == ULTRA_SUM_MIN) hipLaunchKernelGGL(fixup_kernel<ULTRA_SUM_MIN>, dim3(fgrid), dim3(256), 0, stream, fp);
+        else hipLaunchKernelGGL(fixup_kernel<ULTRA_SUM_MAX>, dim3(fgrid), dim3(256), 0, stream, fp);
+        HIP_TRY(hipGetLastError());
+    }
+    return ULTRA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ultra_rspmm_abi_version(void) { return ULTRA_RSPMM_ABI_VERSION; }
+
+const char *ultra_rspmm_status_string(int status) {
+    switch (status) {
+        case ULTRA_OK: return "ok";
+        case ULTRA_ERR_BAD_OP: return "unknown sum/mul operator code";
+        case ULTRA_ERR_BAD_SHAPE: return "bad shape (negative size, F <= 0 or index range beyond int32)";
+        case ULTRA_ERR_NULL_POINTER: return "required pointer is NULL";
+        case ULTRA_ERR_WORKSPACE: return "workspace is NULL or smaller than ultra_rspmm_workspace_bytes()";
+        case ULTRA_ERR_HIP: return "HIP runtime error (see ultra_rspmm_last_hip_error)";
+        case ULTRA_ERR_NO_DEVICE: return "no usable HIP device";
+        default: return "unknown status";
+    }
+}
+
+int ultra_rspmm_last_hip_error(void) { return g_last_hip_error; }
+
+int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_host, size_t arch_len) {
+    DeviceInfo *di = nullptr;
+    int rc = device_info(device, &di);
+    if (rc) return rc;
+    if (n_cu) *n_cu = di->n_cu;
+    if (lds_bytes) *lds_bytes = di->lds_bytes;
+    if (arch_host && arch_len > 0) {
+        std::strncpy(arch_host, di->arch, arch_len - 1);
+        arch_host[arch_len - 1] = 0;
+    }
+    return ULTRA_OK;
+}
+
+size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg, int64_t F) {
+    if (seg == nullptr || F <= 0 || seg->n_pieces <= 0) return 0;
+    return (size_t)seg->n_pieces * (size_t)F * sizeof(float);
+}
+
+int ultra_rspmm_forward_f32(const ultra_segments *fwd, const float *relation, const float *input, const float *add_rows,
+                            float *out, void *workspace, size_t workspace_bytes, int64_t n_rel, int64_t F, int sum_op,
+                            int mul_op, void *stream) {
+    if (fwd == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (fwd->n_rows > 0 && out == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (fwd->n_edges > 0 && (relation == nullptr || input == nullptr)) return ULTRA_ERR_NULL_POINTER;
+    KParams p{};
+    p.relation = relation;
+    p.input = input;
+    p.add_rows = add_rows;
+    p.out = out;
+    return run_plan<KIND_FWD>(fwd, p, n_rel, F, sum_op, mul_op, true, workspace, workspace_bytes,
+                              static_cast<hipStream_t>(stream));
+}
+
+int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments *by_rel, const float *relation,
+                             const float *input, const float *output, const float *output_grad, float *d_input,
+                             float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_rel, int64_t F,
+                             int sum_op, int mul_op, void *stream) {
+    if (output_grad == nullptr || relation == nullptr || input == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (sum_op != ULTRA_SUM_ADD && output == nullptr) return ULTRA_ERR_NULL_POINTER;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d_input != nullptr) {
+        if (by_src == nullptr) return ULTRA_ERR_NULL_POINTER;
+        KParams p{};
+        p.relation = relation;
+        p.input = input;
+        p.output = output;
+        p.grad = output_grad;
+        p.out = d_input;
+        const bool needs_rel = (mul_op == ULTRA_MUL_MUL) || (sum_op != ULTRA_SUM_ADD);
+        int rc = run_plan<KIND_DX>(by_src, p, n_rel, F, sum_op, mul_op, needs_rel, workspace, workspace_bytes, s);
+        if (rc) return rc;
+    }
+    if (d_relation != nullptr) {
+        if (by_rel == nullptr) return ULTRA_ERR_NULL_POINTER;
+        if (by_rel->n_edges > 0 && by_rel->node_b == nullptr) return ULTRA_ERR_NULL_POINTER;
+        KParams p{};
+        p.relation = relation;
+        p.input = input;
+        p.output = output;
+        p.grad = output_grad;
+        p.out = d_relation;
+        int rc = run_plan<KIND_DREL>(by_rel, p, n_rel, F, sum_op, mul_op, false, workspace, workspace_bytes, s);
+        if (rc) return rc;
+    }
+    return ULTRA_OK;
+}
+
+int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd, const float *relation, const float *input,
+                                    const float *output, const float *output_grad, float *d_weight, int64_t n_rel,
+                                    int64_t F, int sum_op, int mul_op, void *stream) {
+    int rc = check_segments(fwd);
+    if (rc) return rc;
+    (void)n_rel;
+    if (F <= 0) return ULTRA_ERR_BAD_SHAPE;
+    if (sum_op < 0 || sum_op > 2 || mul_op < 0 || mul_op > 1) return ULTRA_ERR_BAD_OP;
+    if (fwd->n_edges == 0) return ULTRA_OK;
+    if (relation == nullptr || input == nullptr || output_grad == nullptr || d_weight == nullptr)
+        return ULTRA_ERR_NULL_POINTER;
+    if (sum_op != ULTRA_SUM_ADD && output == nullptr) return ULTRA_ERR_NULL_POINTER;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool unit = fwd->weight == nullptr;
+    long long blocks = (fwd->n_edges + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+#define ULTRA_WCASE(S, M)                                                                                          \
+    if (sum_op == S && mul_op == M) {                                                                              \
+        if (unit)                                                                                                  \
+            hipLaunchKernelGGL((weight_grad_kernel<S, M, true>), dim3((int)blocks), dim3(256), 0, s, fwd->row,     \
+                               fwd->node_a, fwd->rel, fwd->weight, relation, input, output, output_grad, d_weight, \
+                               (long long)F, (long long)fwd->n_edges);                                             \
+        else                                                                                                       \
+            hipLaunchKernelGGL((weight_grad_kernel<S, M, false>), dim3((int)blocks), dim3(256), 0, s, fwd->row,    \
+                               fwd->node_a, fwd->rel, fwd->weight, relation, input, output, output_grad, d_weight, \
+                               (long long)F, (long long)fwd->n_edges);                                             \
+    }
+    ULTRA_WCASE(ULTRA_SUM_ADD, ULTRA_MUL_MUL)
+    ULTRA_WCASE(ULTRA_SUM_ADD, ULTRA_MUL_ADD)
+    ULTRA_WCASE(ULTRA_SUM_MIN, ULTRA_MUL_MUL)
+    ULTRA_WCASE(ULTRA_SUM_MIN, ULTRA_MUL_ADD)
+    ULTRA_WCASE(ULTRA_SUM_MAX, ULTRA_MUL_MUL)
+    ULTRA_WCASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
+#undef ULTRA_WCASE
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+"""Host-side mirror of ``torchdrug.layers.functional.generalized_rspmm`` for the MI355X HIP library.
+
+Reference call sites: ``/root/reference/ultra/layer.py:134-167`` and ``:336-369``, always
+``functional.generalized_rspmm(adjacency, relation_input, input, sum=<"add"|"max"|"min">, mul=<"mul"|"add">)``.
+Same name, argument order, keyword names and error behaviour (unknown operator names raise ``ValueError``;
+shape/device problems raise ``RuntimeError``).  Extension: ``sparse`` may be a cached :class:`RelCSR` instead of
+a 3-D sparse COO tensor, so the sort torchdrug repeats on every call happens once per graph.
+
+Everything numerical happens in ``libultra_rspmm.so``; this module only validates, allocates outputs with
+torch and passes raw pointers plus the current HIP stream across the C ABI.  CPU tensors are rejected: there is
+no fallback (the CPU oracle under ``oracle/`` is test infrastructure and is never imported from here).
+"""
+import collections
+
+import torch
+
+from . import _lib
+from .relcsr import RelCSR
+
+__all__ = ["generalized_rspmm", "rspmm_forward", "RelCSR"]
+
+# Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
+# value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
+_sparse_cache = collections.OrderedDict()
+_SPARSE_CACHE_ENTRIES = 4
+
+
+def _ops(sum, mul):
+    if sum not in _lib.SUM_OPS:
+        raise ValueError("Can't find a rspmm operator for sum=`%s` (expected add, min or max)" % sum)
+    if mul not in _lib.MUL_OPS:
+        raise ValueError("Can't find a rspmm operator for mul=`%s` (expected mul or add)" % mul)
+    return _lib.SUM_OPS[sum], _lib.MUL_OPS[mul]
+
+
+def _as_relcsr(sparse):
+    if isinstance(sparse, RelCSR):
+        return sparse, None
+    if not isinstance(sparse, torch.Tensor) or not sparse.is_sparse:
+        raise TypeError("sparse must be a 3-D torch sparse COO tensor or a RelCSR, got %s" % type(sparse).__name__)
+    idx, val = sparse._indices(), sparse._values()
+    key = (idx.data_ptr(), val.data_ptr(), idx._version, val._version, tuple(sparse.shape))
+    hit = _sparse_cache.get(key)
+    if hit is None:
+        hit = (RelCSR.from_sparse(sparse), idx, val)
+        _sparse_cache[key] = hit
+        while len(_sparse_cache) > _SPARSE_CACHE_ENTRIES:
+            _sparse_cache.popitem(last=False)
+    else:
+        _sparse_cache.move_to_end(key)
+    return hit[0], (val if val.requires_grad else None)
+
+
+def _check_dense(csr, relation, input):
+    n_dst, n_src, n_rel = csr.shape
+    if input.dim() != 2 or relation.dim() != 2:
+        raise RuntimeError("relation and input must be 2-D, got %s and %s" % (tuple(relation.shape), tuple(input.shape)))
+    if input.shape[0] != n_src:
+        raise RuntimeError("Expect input to have %d rows, but found %d" % (n_src, input.shape[0]))
+    if relation.shape[0] != n_rel:
+        raise RuntimeError("Expect relation to have %d rows, but found %d" % (n_rel, relation.shape[0]))
+    if relation.shape[1] != input.shape[1]:
+        raise RuntimeError("Expect relation and input to have the same width, but found %d and %d"
+                           % (relation.shape[1], input.shape[1]))
+    if input.dtype != torch.float32 or relation.dtype != torch.float32:
+        raise RuntimeError("rspmm is fp32 only (TF32 is disabled in the reference, script/run_full.py:19-20)")
+    if not input.is_cuda or not relation.is_cuda:
+        raise RuntimeError("ultra_torchdrug_amd.generalized_rspmm runs on an MI355X (HIP) device only; "
+                           "got input on %s, relation on %s. There is no CPU fallback." % (input.device, relation.device))
+    if input.device != relation.device or input.device != csr.device:
+        raise RuntimeError("sparse, relation and input must be on one device (%s, %s, %s)"
+                           % (csr.device, relation.device, input.device))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(seg, F, device):
+    n = seg.n_pieces * F
+    if n == 0:
+        return None, 0
+    ws = torch.empty(n, dtype=torch.float32, device=device)
+    return ws, n * 4
+
+
+def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None):
+    """Forward only, no autograd.  ``add_rows`` fuses the boundary epilogue of ``layer.py:156,162,358,364``."""
+    sum_op, mul_op = _ops(sum, mul)
+    _check_dense(csr, relation, input)
+    relation, input = relation.contiguous(), input.contiguous()
+    F = input.shape[1]
+    out = torch.empty(csr.shape[0], F, dtype=torch.float32, device=input.device)
+    if add_rows is not None:
+        add_rows = add_rows.contiguous()
+        if add_rows.shape != out.shape or add_rows.dtype != torch.float32 or add_rows.device != out.device:
+            raise RuntimeError("add_rows must be fp32 %s on %s" % (tuple(out.shape), out.device))
+    if out.numel() == 0:
+        return out
+    lib = _lib.load()
+    seg = csr.fwd
+    ws, ws_bytes = _workspace(seg, F, input.device)
+    with torch.cuda.device(input.device):
+        _lib.check(lib.ultra_rspmm_forward_f32(
+            seg.pointer, relation.data_ptr(), input.data_ptr(), add_rows.data_ptr() if add_rows is not None else None,
+            out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, csr.shape[2], F, sum_op, mul_op,
+            _stream()))
+    return out
+
+
+def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mul", need_input=True,
+                   need_relation=True):
+    sum_op, mul_op = _ops(sum, mul)
+    relation, input, output_grad = relation.contiguous(), input.contiguous(), output_grad.contiguous()
+    F = input.shape[1]
+    dev = input.device
+    d_input = torch.empty_like(input) if need_input else None
+    d_relation = torch.empty_like(relation) if need_relation else None
+    if F == 0 or (not need_input and not need_relation):
+        return d_input, d_relation
+    lib = _lib.load()
+    by_src = csr.by_src if need_input else None
+    by_rel = csr.by_rel if need_relation else None
+    n_ws = max(by_src.n_pieces if by_src is not None else 0, by_rel.n_pieces if by_rel is not None else 0) * F
+    ws = torch.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.ultra_rspmm_backward_f32(
+            by_src.pointer if by_src is not None else None, by_rel.pointer if by_rel is not None else None,
+            relation.data_ptr(), input.data_ptr(), output.data_ptr() if output is not None else None,
+            output_grad.data_ptr(), d_input.data_ptr() if d_input is not None else None,
+            d_relation.data_ptr() if d_relation is not None else None, ws.data_ptr() if ws is not None else None,
+            n_ws * 4, csr.shape[2], F, sum_op, mul_op, _stream()))
+    return d_input, d_relation
+
+
+def rspmm_backward_weight(csr, relation, input, output, output_grad, sum="add", mul="mul"):
+    """d(values) of the coalesced edges (forward-plan order)."""
+    sum_op, mul_op = _ops(sum, mul)
+    relation, input, output_grad = relation.contiguous(), input.contiguous(), output_grad.contiguous()
+    d_w = torch.zeros(csr.n_edges, dtype=torch.float32, device=input.device)
+    if csr.n_edges == 0 or input.shape[1] == 0:
+        return d_w
+    lib = _lib.load()
+    with torch.cuda.device(input.device):
+        _lib.check(lib.ultra_rspmm_backward_weight_f32(
+            csr.fwd.pointer, relation.data_ptr(), input.data_ptr(), output.data_ptr() if output is not None else None,
+            output_grad.data_ptr(), d_w.data_ptr(), csr.shape[2], input.shape[1], sum_op, mul_op, _stream()))
+    return d_w
+
+
+class _RSPMMFunction(torch.autograd.Function):
+    """Counterpart of torchdrug's ``RSPMM{Add,Min,Max}{Mul,Add}Function`` autograd classes."""
+
+    @staticmethod
+    def forward(ctx, values, relation, input, csr, sum, mul):
+        out = rspmm_forward(csr, relation, input, sum, mul)
+        ctx.csr, ctx.sum, ctx.mul = csr, sum, mul
+        ctx.values_need_grad = values is not None and values.requires_grad
+        ctx.save_for_backward(relation, input, out if (sum != "add") else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, output_grad):
+        relation, input, out = ctx.saved_tensors
+        need_rel, need_in = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        d_input, d_relation = rspmm_backward(ctx.csr, relation, input, out, output_grad, ctx.sum, ctx.mul,
+                                             need_input=need_in, need_relation=need_rel)
+        d_values = None
+        if ctx.values_need_grad and ctx.needs_input_grad[0]:
+            d_w = rspmm_backward_weight(ctx.csr, relation, input, out, output_grad, ctx.sum, ctx.mul)
+            d_values = d_w[ctx.csr.edge_of_input]   # duplicates of one triple all receive its gradient
+        return d_values, d_relation, d_input, None, None, None
+
+
+def generalized_rspmm(sparse, relation, input, sum="add", mul="mul"):
+    r"""Generalized relational sparse-dense product (drop-in for torchdrug's function of the same name).
+
+    .. math::  out_{v,:} = \bigoplus_{(v, u, r) \in sparse} w_{vur} \cdot (relation_{r,:} \otimes input_{u,:})
+
+    with :math:`\oplus` = ``sum`` in {add, min, max} and :math:`\otimes` = ``mul`` in {mul, add}.
+
+    Parameters: ``sparse`` -- 3-D sparse COO tensor ``(N_dst, N_src, R)`` (any order, duplicates are merged by
+    summing their values, as ``coalesce()`` does) or a :class:`RelCSR`; ``relation`` -- ``(R, F)`` fp32;
+    ``input`` -- ``(N_src, F)`` fp32 (a 1-D ``input`` is treated as ``(N_src, 1)``).  Returns ``(N_dst, F)``.
+    """
+    _ops(sum, mul)
+    csr, values = _as_relcsr(sparse)
+    squeeze = input.dim() == 1
+    if squeeze:
+        input = input.unsqueeze(-1)
+        if relation.dim() == 1:
+            relation = relation.unsqueeze(-1)
+    _check_dense(csr, relation, input)
+    out = _RSPMMFunction.apply(values, relation, input, csr, sum, mul)
+    return out.squeeze(-1) if squeeze else out

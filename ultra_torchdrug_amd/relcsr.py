@@ -1,0 +1,246 @@
+"""RelCSR: the sorted, coalesced edge lists and chunk schedules the HIP kernels walk.
+
+This is the host side of what torchdrug does inside every ``generalized_rspmm`` call -- ``sparse.coalesce()``
+followed by ``coo2csr`` (call sites ``/root/reference/ultra/layer.py:127,328``) -- done
+ONCE per graph and cached, plus the two extra orderings the atomic-free backward needs.
+
+Three reduction plans over the same coalesced edge set (``include/ultra_rspmm.h``, ``ultra_segments``):
+
+=============  ==================  ==========================  ===============================
+plan           target row          sorted by                   used for
+=============  ==================  ==========================  ===============================
+``fwd``        destination node    (dst, src, rel)             forward  (rows of ``out``)
+``by_src``     source node         (src, dst, rel)             ``d_input``
+``by_rel``     relation            (rel, dst, src)             ``d_relation``
+=============  ==================  ==========================  ===============================
+
+A plan's *chunks* are what one wavefront processes: a run of whole rows whose first edges fall in the same
+``chunk_edges``-sized block of the edge list (and in the same ``chunk_rows``-sized block of rows), or one piece
+of ``piece_len`` consecutive edges of a row with more than ``piece_len`` edges.  Pieces are summed separately
+and added in piece order, which is the summation order ``oracle/rspmm_oracle.c`` reproduces with ``piece > 0``.
+
+torch is used here for device memory and sorting only (plumbing).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+CHUNK_EDGES = 64     # target edges per whole-row chunk
+CHUNK_ROWS = 64      # at most this many rows per chunk (bounds the work of runs of empty rows)
+PIECE_LEN = 128      # rows longer than this are cut into pieces of this many edges
+_INT32_MAX = 2 ** 31 - 1
+
+
+class Segments:
+    """One reduction plan; owns the device tensors and the ``ultra_segments`` struct pointing at them."""
+
+    def __init__(self, row, node_a, node_b, rel, weight, n_rows, chunk_edges=CHUNK_EDGES, chunk_rows=CHUNK_ROWS,
+                 piece_len=PIECE_LEN, balance=True):
+        n_edges = int(row.shape[0])
+        if n_rows > _INT32_MAX or n_edges > _INT32_MAX:
+            raise ValueError("graph too large for int32 indices: %d rows, %d edges" % (n_rows, n_edges))
+        self.n_rows, self.n_edges, self.piece_len = int(n_rows), n_edges, int(piece_len)
+        dev = row.device
+        i32 = torch.int32
+        self.row = row.to(i32).contiguous()
+        self.node_a = node_a.to(i32).contiguous()
+        self.node_b = None if node_b is None else node_b.to(i32).contiguous()
+        self.rel = rel.to(i32).contiguous()
+        self.weight = None if weight is None else weight.to(torch.float32).contiguous()
+
+        deg = torch.bincount(row, minlength=n_rows) if n_edges else torch.zeros(n_rows, dtype=torch.long, device=dev)
+        row_ptr = torch.zeros(n_rows + 1, dtype=torch.long, device=dev)
+        torch.cumsum(deg, 0, out=row_ptr[1:])
+        self.row_ptr = row_ptr
+        chunks, long_rows, n_pieces = _schedule(row_ptr, deg, chunk_edges, chunk_rows, piece_len, balance)
+        self.chunks = chunks.to(i32).contiguous()
+        self.long_rows = long_rows.to(i32).contiguous()
+        self.n_pieces = int(n_pieces)
+
+        self.struct = _lib.UltraSegments()
+        self._refresh_struct()
+
+    def _refresh_struct(self):
+        s = self.struct
+        s.n_rows, s.n_edges = self.n_rows, self.n_edges
+        s.row = self.row.data_ptr()
+        s.node_a = self.node_a.data_ptr()
+        s.node_b = self.node_b.data_ptr() if self.node_b is not None else None
+        s.rel = self.rel.data_ptr()
+        s.weight = self.weight.data_ptr() if self.weight is not None else None
+        s.n_chunks = int(self.chunks.shape[0])
+        s.chunks = self.chunks.data_ptr()
+        s.n_long_rows = int(self.long_rows.shape[0])
+        s.long_rows = self.long_rows.data_ptr()
+        s.n_pieces = self.n_pieces
+        s.piece_len = self.piece_len
+
+    @property
+    def pointer(self):
+        return ctypes.byref(self.struct)
+
+    @property
+    def device(self):
+        return self.row.device
+
+
+def _schedule(row_ptr, deg, chunk_edges, chunk_rows, piece_len, balance):
+    """Vectorised chunk schedule.  Returns (chunks [n,4], long_rows [m,3], n_pieces)."""
+    dev = row_ptr.device
+    n_rows = deg.shape[0]
+    if n_rows == 0:
+        return (torch.zeros(0, 4, dtype=torch.long, device=dev), torch.zeros(0, 3, dtype=torch.long, device=dev), 0)
+    rows = torch.arange(n_rows, device=dev)
+    is_long = deg > piece_len
+    blk = torch.div(row_ptr[:-1], chunk_edges, rounding_mode="floor")
+    rblk = torch.div(rows, chunk_rows, rounding_mode="floor")
+    start = torch.ones(n_rows, dtype=torch.bool, device=dev)
+    start[1:] = (blk[1:] != blk[:-1]) | (rblk[1:] != rblk[:-1]) | is_long[1:] | is_long[:-1]
+    g_first = torch.nonzero(start).flatten()
+    g_last = torch.cat([g_first[1:], torch.tensor([n_rows], device=dev)])
+    g_long = is_long[g_first]
+
+    nf, nl = g_first[~g_long], g_last[~g_long]
+    normal = torch.stack([row_ptr[nf], row_ptr[nl], nf, nl], dim=1)
+
+    lrow = g_first[g_long]
+    if lrow.numel():
+        ldeg = deg[lrow]
+        n_p = torch.div(ldeg + piece_len - 1, piece_len, rounding_mode="floor")
+        first_slot = torch.cumsum(n_p, 0) - n_p
+        n_pieces = int(n_p.sum().item())
+        owner = torch.repeat_interleave(torch.arange(lrow.numel(), device=dev), n_p)
+        k = torch.arange(n_pieces, device=dev) - first_slot[owner]
+        e_begin = row_ptr[lrow][owner] + k * piece_len
+        e_end = torch.minimum(e_begin + piece_len, row_ptr[lrow + 1][owner])
+        slot = first_slot[owner] + k
+        pieces = torch.stack([e_begin, e_end, lrow[owner], -(slot + 1)], dim=1)
+        long_rows = torch.stack([lrow, first_slot, n_p], dim=1)
+        chunks = torch.cat([pieces, normal], dim=0)
+    else:
+        n_pieces = 0
+        long_rows = torch.zeros(0, 3, dtype=torch.long, device=dev)
+        chunks = normal
+    if balance and chunks.shape[0] > 1:
+        # heaviest first: the kernel deals chunks round-robin to wavefronts, so every wavefront gets a similar mix
+        cost = (chunks[:, 1] - chunks[:, 0]) * 4 + torch.where(chunks[:, 3] < 0, torch.ones_like(chunks[:, 3]),
+                                                                chunks[:, 3] - chunks[:, 2])
+        order = torch.sort(cost, descending=True, stable=True).indices
+        chunks = chunks[order]
+    return chunks, long_rows, n_pieces
+
+
+def _sum_duplicates(weight, first, count):
+    """Sequential (input-order) fp32 sum of each run of duplicates; deterministic, unlike index_add_."""
+    acc = weight[first].clone()
+    max_count = int(count.max().item()) if count.numel() else 1
+    for j in range(1, max_count):
+        has = count > j
+        idx = first[has] + j
+        acc[has] = acc[has] + weight[idx]
+    return acc
+
+
+class RelCSR:
+    """Coalesced relational adjacency of shape ``(n_dst, n_src, n_rel)`` plus its reduction plans."""
+
+    def __init__(self, dst, src, rel, weight, n_dst, n_src, n_rel, chunk_edges=CHUNK_EDGES, chunk_rows=CHUNK_ROWS,
+                 piece_len=PIECE_LEN, balance=True):
+        """``dst/src/rel``: int64 tensors [E] (any order, duplicates allowed); ``weight``: fp32 [E] or None (ones)."""
+        dev = dst.device
+        dst, src, rel = dst.long(), src.long(), rel.long()
+        n_dst, n_src, n_rel = int(n_dst), int(n_src), int(n_rel)
+        if dst.numel():
+            lo = min(int(dst.min()), int(src.min()), int(rel.min()))
+            if lo < 0 or int(dst.max()) >= n_dst or int(src.max()) >= n_src or int(rel.max()) >= n_rel:
+                raise ValueError("edge index out of range for adjacency (%d, %d, %d)" % (n_dst, n_src, n_rel))
+        if float(n_dst) * float(n_src) * float(max(n_rel, 1)) >= 2.0 ** 62:
+            raise ValueError("adjacency too large for a 64-bit sort key")
+        self.shape = (n_dst, n_src, n_rel)
+        self._opts = dict(chunk_edges=chunk_edges, chunk_rows=chunk_rows, piece_len=piece_len, balance=balance)
+        if weight is None:
+            weight = torch.ones(dst.shape[0], dtype=torch.float32, device=dev)
+        weight = weight.to(torch.float32)
+
+        # coalesce: sort by (dst, src, rel), merge duplicate triples by summing their weights
+        key = (dst * n_src + src) * max(n_rel, 1) + rel
+        key, order = torch.sort(key, stable=True)
+        if key.numel():
+            uniq, inverse, count = torch.unique_consecutive(key, return_inverse=True, return_counts=True)
+            first = torch.cumsum(count, 0) - count
+            w_sorted = weight[order]
+            w_merged = _sum_duplicates(w_sorted, first, count) if uniq.numel() != key.numel() else w_sorted
+            sel = order[first]
+            dst, src, rel = dst[sel], src[sel], rel[sel]
+            # position of every ORIGINAL edge in the coalesced list (for d_weight of a sparse tensor that requires grad)
+            self.edge_of_input = torch.empty_like(order)
+            self.edge_of_input[order] = inverse
+        else:
+            w_merged = weight
+            self.edge_of_input = torch.zeros(0, dtype=torch.long, device=dev)
+        self.dst, self.src, self.rel_id = dst, src, rel
+        self.unit_weight = bool((w_merged == 1).all().item()) if w_merged.numel() else True
+        self.weight = w_merged
+        self.n_edges = int(dst.shape[0])
+        self._fwd = self._by_src = self._by_rel = None
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_sparse(cls, sparse, **opts):
+        """From the 3-D sparse COO ``(N_dst, N_src, R)`` the reference passes (``layer.py:127,328``)."""
+        if not sparse.is_sparse or sparse.dim() != 3:
+            raise ValueError("expected a 3-D sparse COO tensor (N_dst, N_src, R), got %s" % (tuple(sparse.shape),))
+        idx = sparse._indices()
+        return cls(idx[0], idx[1], idx[2], sparse._values(), *sparse.shape, **opts)
+
+    @classmethod
+    def from_edge_list(cls, edge_list, edge_weight, num_node, num_relation, **opts):
+        """From a torchdrug-style ``edge_list`` of (node_in, node_out, relation) rows: ``adjacency.transpose(0, 1)``
+        as the layers use it (``layer.py:56,127``), i.e. destination = node_out, source = node_in."""
+        return cls(edge_list[:, 1], edge_list[:, 0], edge_list[:, 2], edge_weight, num_node, num_node, num_relation,
+                   **opts)
+
+    # ------------------------------------------------------------------ plans
+    @property
+    def device(self):
+        return self.dst.device
+
+    def _w(self, order=None):
+        if self.unit_weight:
+            return None
+        return self.weight if order is None else self.weight[order]
+
+    @property
+    def fwd(self):
+        if self._fwd is None:
+            self._fwd = Segments(self.dst, self.src, None, self.rel_id, self._w(), self.shape[0], **self._opts)
+        return self._fwd
+
+    @property
+    def by_src(self):
+        if self._by_src is None:
+            n_dst, n_src, n_rel = self.shape
+            key = (self.src * n_dst + self.dst) * max(n_rel, 1) + self.rel_id
+            order = torch.sort(key, stable=True).indices
+            self._by_src_order = order
+            self._by_src = Segments(self.src[order], self.dst[order], None, self.rel_id[order], self._w(order), n_src,
+                                    **self._opts)
+        return self._by_src
+
+    @property
+    def by_rel(self):
+        if self._by_rel is None:
+            n_dst, n_src, n_rel = self.shape
+            key = (self.rel_id * n_dst + self.dst) * n_src + self.src
+            order = torch.sort(key, stable=True).indices
+            self._by_rel_order = order
+            self._by_rel = Segments(self.rel_id[order], self.src[order], self.dst[order], self.rel_id[order],
+                                    self._w(order), n_rel, **self._opts)
+        return self._by_rel
+
+    def degree_in(self):
+        """Weighted in-degree per destination row (``graph.degree_out`` of the transposed adjacency)."""
+        out = torch.zeros(self.shape[0], dtype=torch.float32, device=self.device)
+        return out.index_add_(0, self.dst, self.weight)
