@@ -1,0 +1,243 @@
+"""bench.py -- edges aggregated / second of the rspmm Bellman-Ford hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched by
+``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json metric: "edges aggregated/sec ... FB15k237 6L x 64d rspmm"): S-fb15k237 -- a seeded
+synthetic KG of FB15k237's size (N=14 541, 272 115 triples, 237 relations => E=544 230, R=474 after inverse
+edges), seeded random-init Ultra weights (6 x 64d entity stack + 6 x 64d relation stack).
+One STEP = one evaluation batch of B=16 test triples through ``predict`` (/root/reference/ultra/task.py:228-263):
+relation-graph Bellman-Ford (6 rspmm) + tail pass + head pass over all N candidates (2 x 6 rspmm + epilogues +
+score MLP) = 18 rspmm calls, exactly the reference's unit of evaluation work.  Unit of work = one edge message =
+one edge x one batch element x 64 fp32 lanes; a step aggregates 12*E*B + 6*E_rel*B of them.  All inputs are
+resident in HBM before the timed region.  Multi-GPU: every rank holds the graph and evaluates its own query
+batch (query sharding, no data-path collective) => weak scaling.
+
+Also reported on the same line: ``roofline`` for the dominant kernel (entity-graph rspmm forward; HIP events
+recorded around exactly that kernel on its stream, inside the timed region) and ``cpu_baseline`` (the CPU oracle's
+row loop -- a restatement of the torchdrug CPU algorithm, kind "port" -- timed on this box's host cores on one
+rspmm call of the same graph).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+class HipEvents:
+    """Raw hipEvent_t pairs (the C ABI's profile hook records them on the kernel's own stream)."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self.pairs = []
+
+    def new_pair(self):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
+        self.pairs.append((a, b))
+        return a, b
+
+    def elapsed_ms(self):
+        out = []
+        for a, b in self.pairs:
+            self.hip.hipEventSynchronize(b)
+            ms = ctypes.c_float()
+            assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+            out.append(ms.value)
+        return out
+
+
+def bytes_algo(E, N, R, F):
+    """every edge gathers one F-wide fp32 source row and a 12-byte (src, rel, w) triple; every
+    destination row is written once; relation table and row pointers are read once."""
+    return E * (4 * F + 12) + 4 * N * F + 4 * R * F + 4 * (N + 1)
+
+
+def cpu_baseline(graph_np, n_node, n_rel, F, budget_s=20.0):
+    """The oracle's CSR row loop (OpenMP over rows) on ONE rspmm call of the bench graph; rank 0, N=1 only."""
+    from oracle import oracle as O
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    O.build()
+    rng = np.random.default_rng(1024)
+    csr = O.coalesce_csr(graph_np["dst"], graph_np["src"], graph_np["rel"], None, n_node, n_node, n_rel)
+    relation = rng.standard_normal((n_rel, F)).astype(np.float32)
+    x = rng.standard_normal((n_node, F)).astype(np.float32)
+    O.rspmm_forward(csr, relation, x, "add", "mul")            # warm-up (page-in, thread pool)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 10 and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        O.rspmm_forward(csr, relation, x, "add", "mul")
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": csr.n_edges * (F // 64) / med, "unit": "edges aggregated/s", "cores": threads,
+            "kind": "port",
+            "sample": "%d x one rspmm forward (add,mul) on S-fb15k237, E=%d, F=%d (B=%d); median %.3f s; "
+                      "oracle/rspmm_oracle.c row loop, OpenMP, restatement of the torchdrug CPU algorithm"
+                      % (len(times), csr.n_edges, F, F // 64, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="queries per step (reference inference batch: 16)")
+    ap.add_argument("--workload", default="S-fb15k237")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mrr-queries", type=int, default=64, help="seeded test triples ranked after the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch N ranks with torch.distributed.run for --gpus N"
+
+    import ultra_torchdrug_amd as U
+    from ultra_torchdrug_amd import _lib
+    from ultra_torchdrug_amd.data import synthetic_triples, DEFAULT_SEED
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    lib = U.require_library()
+    torch.backends.cuda.matmul.allow_tf32 = False          # script/run_full.py:19-20
+    torch.backends.cudnn.allow_tf32 = False
+
+    # ---------------- graph, split, model (identical on every rank) ----------------
+    triples, n_node, n_rel = synthetic_triples(args.workload, DEFAULT_SEED)
+    rng = np.random.default_rng(DEFAULT_SEED)
+    n_test = min(2048, len(triples) // 20)
+    test_idx = rng.choice(len(triples), n_test, replace=False)
+    fact_mask = np.ones(len(triples), dtype=bool)
+    # the bench graph keeps ALL synthetic triples as facts (E = 2 x triples as BASELINE.md states);
+    # test queries are drawn from them and filtered against the same graph.
+    graph = Graph(torch.from_numpy(triples), num_node=n_node, num_relation=n_rel)
+    torch.manual_seed(DEFAULT_SEED)
+    task = build_ultra(n_rel)
+    task.preprocess(graph, torch.from_numpy(fact_mask))
+    task.to(dev).eval()
+    und = task.model._undirected(task.fact_graph)
+    E, R2 = und.relcsr.n_edges, und.num_relation
+    E_rel = task.rel_graphs[0].relcsr.n_edges
+    for g in (und, task.rel_graphs[0]):
+        _ = g.relcsr.fwd                                      # plans built before the timed region
+    B = args.batch
+    F = B * 64
+    edges_per_step = (12 * E + 6 * E_rel) * B
+
+    # each rank evaluates its own strided shard of the seeded test triples (DistributedSampler-style)
+    test = torch.from_numpy(triples[test_idx]).to(dev)
+    shard = test[rank::world]
+    n_batches = max(len(shard) // B, 1)
+
+    def step(i):
+        batch = shard[(i % n_batches) * B:(i % n_batches) * B + B]
+        return task.predict(batch)
+
+    # profile hook: events around the entity-graph forward segment kernel (the dominant kernel)
+    events = HipEvents()
+    from ultra_torchdrug_amd import functional as UF
+    real_forward = UF.rspmm_forward
+    state = {"on": False}
+
+    def timed_forward(csr, relation, input, sum="add", mul="mul", add_rows=None):
+        if state["on"] and csr is und.relcsr:
+            a, b = events.new_pair()
+            lib.ultra_rspmm_profile_next(a, b)
+        return real_forward(csr, relation, input, sum, mul, add_rows)
+
+    UF.rspmm_forward = timed_forward
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        state["on"] = True
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        state["on"] = False
+    UF.rspmm_forward = real_forward
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    kernel_ms = events.elapsed_ms()
+    k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    algo = bytes_algo(E, n_node, R2, F)
+
+    # ---------------- MRR of the HIP path on seeded queries (after the timed region) ----------------
+    mrr = None
+    if args.mrr_queries > 0:
+        with torch.no_grad():
+            ranks = [task.rank_batch(shard[i:i + B]) for i in range(0, min(args.mrr_queries, len(shard)), B)]
+        ranks = torch.cat(ranks)
+        mrr = float((1.0 / ranks.float()).mean())
+
+    if rank == 0:
+        result = {
+            "metric": "edges aggregated/sec, FB15k237-shaped 6L x 64d rspmm Bellman-Ford (predict: 18 rspmm/batch)",
+            "value": edges_per_step * args.steps * world / elapsed,
+            "unit": "edges aggregated/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s N=%d E=%d R=%d B=%d F=%d, 6+6 layers x 64d, predict() tail+head over all "
+                                   "entities (E_rel=%d)" % (args.workload, n_node, E, R2, B, F, E_rel),
+                       "global_batch": B * world, "parallelism": "query-sharded replicas x%d" % world},
+            "edges_per_step": edges_per_step,
+            "rspmm_kernel_only": {"kernel": "segment_kernel<FWD,add,mul,unit_w,rel_lds> (entity graph)",
+                                  "launches_timed": len(kernel_ms), "avg_ms": k_avg_ms,
+                                  "edges_per_s": E * B / (k_avg_ms * 1e-3) if kernel_ms else None},
+            "roofline": {"bound": "hbm", "achieved": algo / (k_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "algorithmic bytes/launch = %d (SURVEY 8d); input (%.0f MB) is Infinity-Cache/L2 "
+                                 "resident at this size, so achieved may exceed HBM peak" % (algo, n_node * F * 4 / 1e6)},
+            "mrr_hip": mrr,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            und_np = {"dst": und.edge_list[:, 1].cpu().numpy(), "src": und.edge_list[:, 0].cpu().numpy(),
+                      "rel": und.edge_list[:, 2].cpu().numpy()}
+            result["cpu_baseline"] = cpu_baseline(und_np, n_node, R2, F)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

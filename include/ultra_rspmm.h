@@ -47,7 +47,7 @@ enum ultra_mul_op { ULTRA_MUL_MUL = 0, ULTRA_MUL_ADD = 1 };
 enum ultra_status {
     ULTRA_OK = 0,
     ULTRA_ERR_BAD_OP = 1,        /* unknown sum/mul code (the Python side raises ValueError first) */
-    ULTRA_ERR_BAD_SHAPE = 2,     /* F not a multiple of 64, negative sizes, index range overflow */
+    ULTRA_ERR_BAD_SHAPE = 2,     /* F <= 0, negative sizes, index range beyond int32 */
     ULTRA_ERR_NULL_POINTER = 3,
     ULTRA_ERR_WORKSPACE = 4,     /* workspace smaller than ultra_rspmm_workspace_bytes() */
     ULTRA_ERR_HIP = 5,           /* a HIP runtime call failed; see ultra_rspmm_last_hip_error() */
@@ -79,6 +79,13 @@ int ultra_rspmm_last_hip_error(void);
 
 /* Fills n_cu (compute units), lds_bytes (per workgroup limit), arch (e.g. "gfx950", buffer >= 32 B). */
 int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_host, size_t arch_len);
+
+/*
+ * Measurement aid (bench.py): the NEXT forward/backward plan launched from this thread records `start_event`
+ * right before and `stop_event` right after its main segment kernel, on the stream of that call (hipEvent_t
+ * handles owned by the caller, passed as void*; NULL = off).  One-shot: cleared by the call that uses it.
+ */
+int ultra_rspmm_profile_next(void *start_event, void *stop_event);
 
 /* Scratch bytes a call over `seg` with row width F needs (piece partial sums). */
 size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg_host, int64_t F);

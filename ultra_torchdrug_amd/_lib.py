@@ -38,6 +38,7 @@ EXPORTS = (
     "ultra_rspmm_status_string",
     "ultra_rspmm_last_hip_error",
     "ultra_rspmm_device_info",
+    "ultra_rspmm_profile_next",
     "ultra_rspmm_workspace_bytes",
     "ultra_rspmm_forward_f32",
     "ultra_rspmm_backward_f32",
@@ -78,6 +79,8 @@ def load():
     lib.ultra_rspmm_last_hip_error.argtypes = []
     lib.ultra_rspmm_device_info.restype = i32
     lib.ultra_rspmm_device_info.argtypes = [i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.c_char_p, sz]
+    lib.ultra_rspmm_profile_next.restype = i32
+    lib.ultra_rspmm_profile_next.argtypes = [vp, vp]
     lib.ultra_rspmm_workspace_bytes.restype = sz
     lib.ultra_rspmm_workspace_bytes.argtypes = [seg, i64]
     lib.ultra_rspmm_forward_f32.restype = i32

@@ -309,6 +309,9 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(const int32_t *row, co
 // ------------------------------------------------------------------------------------------------ host side
 
 thread_local int g_last_hip_error = 0;
+// one-shot profiling events (ultra_rspmm_profile_next): bracket the next plan's segment kernel on its stream
+thread_local hipEvent_t g_prof_start = nullptr;
+thread_local hipEvent_t g_prof_stop = nullptr;
 
 #define HIP_TRY(expr)                                   \
     do {                                                \
@@ -449,8 +452,12 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t n_rel, int64_t F, int
     p.blocks_per_label = blocks_per_label;
 
     const int grid = blocks_per_label * kXcd;
+    hipEvent_t ev_start = g_prof_start, ev_stop = g_prof_stop;
+    g_prof_start = g_prof_stop = nullptr;
+    if (ev_start != nullptr) HIP_TRY(hipEventRecord(ev_start, stream));
     rc = launch_ops<KIND>(p, sum_op, mul_op, seg->weight == nullptr, rel_lds, grid, rel_lds ? lds_need : 0, stream);
     if (rc) return rc;
+    if (ev_stop != nullptr) HIP_TRY(hipEventRecord(ev_stop, stream));
 
     if (seg->n_long_rows > 0) {
         FixParams fp;
@@ -503,6 +510,12 @@ int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_ho
         std::strncpy(arch_host, di->arch, arch_len - 1);
         arch_host[arch_len - 1] = 0;
     }
+    return ULTRA_OK;
+}
+
+int ultra_rspmm_profile_next(void *start_event, void *stop_event) {
+    g_prof_start = static_cast<hipEvent_t>(start_event);
+    g_prof_stop = static_cast<hipEvent_t>(stop_event);
     return ULTRA_OK;
 }
 

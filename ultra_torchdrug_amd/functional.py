@@ -48,7 +48,7 @@ def _as_relcsr(sparse):
             _sparse_cache.popitem(last=False)
     else:
         _sparse_cache.move_to_end(key)
-    return hit[0], (val if val.requires_grad else None)
+    return hit[0], (sparse if sparse.requires_grad else None)
 
 
 def _check_dense(csr, relation, input):
@@ -152,10 +152,12 @@ class _RSPMMFunction(torch.autograd.Function):
     """Counterpart of torchdrug's ``RSPMM{Add,Min,Max}{Mul,Add}Function`` autograd classes."""
 
     @staticmethod
-    def forward(ctx, values, relation, input, csr, sum, mul):
+    def forward(ctx, sparse, relation, input, csr, sum, mul):
         out = rspmm_forward(csr, relation, input, sum, mul)
         ctx.csr, ctx.sum, ctx.mul = csr, sum, mul
-        ctx.values_need_grad = values is not None and values.requires_grad
+        ctx.sparse_meta = None
+        if sparse is not None and sparse.requires_grad:
+            ctx.sparse_meta = (sparse._indices(), tuple(sparse.shape))
         ctx.save_for_backward(relation, input, out if (sum != "add") else None)
         return out
 
@@ -165,11 +167,13 @@ class _RSPMMFunction(torch.autograd.Function):
         need_rel, need_in = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         d_input, d_relation = rspmm_backward(ctx.csr, relation, input, out, output_grad, ctx.sum, ctx.mul,
                                              need_input=need_in, need_relation=need_rel)
-        d_values = None
-        if ctx.values_need_grad and ctx.needs_input_grad[0]:
+        d_sparse = None
+        if ctx.sparse_meta is not None and ctx.needs_input_grad[0]:
             d_w = rspmm_backward_weight(ctx.csr, relation, input, out, output_grad, ctx.sum, ctx.mul)
-            d_values = d_w[ctx.csr.edge_of_input]   # duplicates of one triple all receive its gradient
-        return d_values, d_relation, d_input, None, None, None
+            indices, shape = ctx.sparse_meta
+            # duplicates of one triple all receive its gradient
+            d_sparse = torch.sparse_coo_tensor(indices, d_w[ctx.csr.edge_of_input], shape)
+        return d_sparse, d_relation, d_input, None, None, None
 
 
 def generalized_rspmm(sparse, relation, input, sum="add", mul="mul"):
@@ -184,12 +188,12 @@ def generalized_rspmm(sparse, relation, input, sum="add", mul="mul"):
     ``input`` -- ``(N_src, F)`` fp32 (a 1-D ``input`` is treated as ``(N_src, 1)``).  Returns ``(N_dst, F)``.
     """
     _ops(sum, mul)
-    csr, values = _as_relcsr(sparse)
+    csr, sparse_leaf = _as_relcsr(sparse)
     squeeze = input.dim() == 1
     if squeeze:
         input = input.unsqueeze(-1)
         if relation.dim() == 1:
             relation = relation.unsqueeze(-1)
     _check_dense(csr, relation, input)
-    out = _RSPMMFunction.apply(values, relation, input, csr, sum, mul)
+    out = _RSPMMFunction.apply(sparse_leaf, relation, input, csr, sum, mul)
     return out.squeeze(-1) if squeeze else out

@@ -1,0 +1,221 @@
+"""Relational convolution layers of the NBFNet Bellman-Ford iteration, on top of the HIP rspmm.
+
+Mirrors ``/root/reference/ultra/layer.py``:
+
+* :class:`GeneralizedRelationalConvNBF`     -- ``layer.py:14-190``  (relation-graph stack, ``dependent=False``)
+* :class:`GeneralizedRelationalConvNBFMod`  -- ``layer.py:193-392`` (entity stack, ``project=True``)
+
+Same constructor arguments, attribute / parameter names (``linear``, ``layer_norm``, ``relation``,
+``relation_linear``, ``relation_projection.layers.{0,1}``) and aggregate functions, so reference state dicts load
+unchanged.  The two reference classes repeat the same aggregation code; here it lives once in
+:class:`_RelationalConvBase`.  ``forward = combine(input, message_and_aggregate(graph, input))`` is the contract
+of torchdrug's ``MessagePassingBase``.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import functional
+
+
+class MLP(nn.Module):
+    """``torchdrug.layers.MLP`` as the reference uses it: Linear layers in ``self.layers``, activation between
+    them, none after the last (``ultra/layer.py:228``, ``ultra/model.py:53``, ``ultra/rel_model.py:263``)."""
+
+    def __init__(self, input_dim, hidden_dims, short_cut=False, activation="relu"):
+        super().__init__()
+        if isinstance(hidden_dims, int):
+            hidden_dims = [hidden_dims]
+        self.dims = [input_dim] + list(hidden_dims)
+        self.short_cut = short_cut
+        self.activation = getattr(F, activation) if isinstance(activation, str) else activation
+        self.layers = nn.ModuleList(nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(len(self.dims) - 1))
+
+    def forward(self, input):
+        layer_input = input
+        for i, layer in enumerate(self.layers):
+            hidden = layer(layer_input)
+            if i < len(self.layers) - 1 and self.activation:
+                hidden = self.activation(hidden)
+            if self.short_cut and hidden.shape == layer_input.shape:
+                hidden = hidden + layer_input
+            layer_input = hidden
+        return hidden
+
+
+class _RelationalConvBase(nn.Module):
+    eps = 1e-6
+    message2mul = {"transe": "add", "distmult": "mul"}   # layer.py:18-21
+
+    def _init_common(self, input_dim, output_dim, num_relation, query_input_dim, message_func, aggregate_func,
+                     layer_norm, activation):
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.num_relation = num_relation
+        self.query_input_dim = query_input_dim
+        self.message_func = message_func
+        self.aggregate_func = aggregate_func
+        self.layer_norm = nn.LayerNorm(output_dim) if layer_norm else None
+        self.activation = getattr(F, activation) if isinstance(activation, str) else activation
+        width = 13 if aggregate_func in ("pna", "pna_nobound") else 2    # layer.py:43-46
+        self.linear = nn.Linear(input_dim * width, output_dim)
+
+    # ---- subclasses provide the (num_relation, batch, dim)-shaped relation table ------------------------
+    def _relation_table(self, graph, batch_size):
+        raise NotImplementedError
+
+    def forward(self, graph, input):
+        update = self.message_and_aggregate(graph, input)
+        return self.combine(input, update)
+
+    # ---- O(E) definition, used for rotate / graphs that require grad (layer.py:52-109, :232-296) ---------
+    def message(self, graph, input):
+        batch_size = len(graph.query)
+        node_in, node_out, relation = graph.edge_list.t()
+        relation_input = self._relation_table(graph, batch_size)          # (R, B, D)
+        node_input = input[node_in]
+        edge_input = relation_input[relation]
+        if self.message_func == "transe":
+            message = edge_input + node_input
+        elif self.message_func == "distmult":
+            message = edge_input * node_input
+        elif self.message_func == "rotate":
+            node_re, node_im = node_input.chunk(2, dim=-1)
+            edge_re, edge_im = edge_input.chunk(2, dim=-1)
+            message = torch.cat([node_re * edge_re - node_im * edge_im, node_re * edge_im + node_im * edge_re], dim=-1)
+        else:
+            raise ValueError("Unknown message function `%s`" % self.message_func)
+        return torch.cat([message, graph.boundary])
+
+    def aggregate(self, graph, message):
+        n = graph.num_node
+        node_out = torch.cat([graph.edge_list[:, 1], torch.arange(n, device=graph.device)])
+        edge_weight = torch.cat([graph.edge_weight, torch.ones(n, device=graph.device)]).unsqueeze(-1).unsqueeze(-1)
+        degree_out = graph.degree_out.unsqueeze(-1).unsqueeze(-1) + 1
+        index = node_out.view(-1, 1, 1).expand_as(message)
+        weighted = message * edge_weight
+
+        def scatter(src, reduce):
+            out = torch.zeros(n, *message.shape[1:], device=message.device, dtype=message.dtype)
+            return out.scatter_reduce(0, index, src, reduce=reduce, include_self=False)
+
+        if self.aggregate_func == "sum":
+            return scatter(weighted, "sum")
+        if self.aggregate_func == "mean":
+            return scatter(weighted, "mean")
+        if self.aggregate_func == "max":
+            return scatter(weighted, "amax")
+        if self.aggregate_func == "pna":
+            mean = scatter(weighted, "mean")
+            sq_mean = scatter(message ** 2 * edge_weight, "mean")
+            return self._pna(mean, sq_mean, scatter(weighted, "amax"), scatter(weighted, "amin"), degree_out)
+        raise ValueError("Unknown aggregation function `%s`" % self.aggregate_func)
+
+    def _pna(self, mean, sq_mean, max, min, degree_out):
+        # layer.py:147-153 / :172-178
+        std = (sq_mean - mean ** 2).clamp(min=self.eps).sqrt()
+        features = torch.cat([mean.unsqueeze(-1), max.unsqueeze(-1), min.unsqueeze(-1), std.unsqueeze(-1)], dim=-1)
+        features = features.flatten(-2)
+        scale = degree_out.log()
+        scale = scale / scale.mean()
+        scales = torch.cat([torch.ones_like(scale), scale, 1 / scale.clamp(min=1e-2)], dim=-1)
+        return (features.unsqueeze(-1) * scales.unsqueeze(-2)).flatten(-2)
+
+    # ---- rspmm path (layer.py:111-182, :298-384) -------------------------------------------------------
+    def message_and_aggregate(self, graph, input):
+        if graph.requires_grad or self.message_func == "rotate":
+            return self.aggregate(graph, self.message(graph, input))
+        if self.message_func not in self.message2mul:
+            raise ValueError("Unknown message function `%s`" % self.message_func)
+        mul = self.message2mul[self.message_func]
+
+        batch_size = len(graph.query)
+        input = input.flatten(1)
+        boundary = graph.boundary.flatten(1)
+        relation_input = self._relation_table(graph, batch_size).flatten(1)    # (R, B*D)
+        adjacency = graph.relcsr        # cached plans of graph.adjacency.transpose(0, 1)
+        func = self.aggregate_func
+        bound = not func.endswith("_nobound")
+        kind = func[:-len("_nobound")] if not bound else func
+        rspmm = functional.generalized_rspmm
+
+        if kind not in ("sum", "mean", "max", "pna"):
+            raise ValueError("Unknown aggregation function `%s`" % self.aggregate_func)
+        degree_out = None
+        if kind in ("mean", "pna"):
+            degree_out = graph.degree_out.unsqueeze(-1) + 1
+        if kind in ("sum", "mean"):
+            update = rspmm(adjacency, relation_input, input, sum="add", mul=mul)
+            if bound:
+                update = update + boundary
+            if kind == "mean":
+                update = update / degree_out
+        elif kind == "max":
+            update = rspmm(adjacency, relation_input, input, sum="max", mul=mul)
+            if bound:
+                update = torch.max(update, boundary)
+        else:
+            sum = rspmm(adjacency, relation_input, input, sum="add", mul=mul)
+            sq_sum = rspmm(adjacency, relation_input ** 2, input ** 2, sum="add", mul=mul)
+            max = rspmm(adjacency, relation_input, input, sum="max", mul=mul)
+            min = rspmm(adjacency, relation_input, input, sum="min", mul=mul)
+            if bound:
+                sum, sq_sum = sum + boundary, sq_sum + boundary ** 2
+                max, min = torch.max(max, boundary), torch.min(min, boundary)
+            update = self._pna(sum / degree_out, sq_sum / degree_out, max, min, degree_out)
+        return update.view(len(update), batch_size, -1)
+
+    def combine(self, input, update):
+        # layer.py:184-190 / :386-392
+        output = self.linear(torch.cat([input, update], dim=-1))
+        if self.layer_norm:
+            output = self.layer_norm(output)
+        if self.activation:
+            output = self.activation(output)
+        return output
+
+
+class GeneralizedRelationalConvNBF(_RelationalConvBase):
+    """``ultra/layer.py:14-190``.  ``dependent``: relation table is a linear map of the query (``:48,58,123``);
+    otherwise a learned ``nn.Embedding`` shared by the whole batch (``:50,60,126``)."""
+
+    def __init__(self, input_dim, output_dim, num_relation, query_input_dim, message_func="distmult",
+                 aggregate_func="pna", layer_norm=False, activation="relu", dependent=True):
+        super().__init__()
+        self._init_common(input_dim, output_dim, num_relation, query_input_dim, message_func, aggregate_func,
+                          layer_norm, activation)
+        self.dependent = dependent
+        if dependent:
+            self.relation_linear = nn.Linear(query_input_dim, num_relation * input_dim)
+        else:
+            self.relation = nn.Embedding(num_relation, input_dim)
+
+    def _relation_table(self, graph, batch_size):
+        assert graph.num_relation == self.num_relation     # layer.py:53,115
+        if self.dependent:
+            table = self.relation_linear(graph.query).view(batch_size, self.num_relation, self.input_dim)
+            return table.transpose(0, 1)
+        return self.relation.weight.unsqueeze(1).expand(-1, batch_size, -1)
+
+
+class GeneralizedRelationalConvNBFMod(_RelationalConvBase):
+    """``ultra/layer.py:193-392``.  ``self.relation`` is installed by the caller before every forward
+    (``ultra/model.py:149-156``): either ``(R, D)`` or per-query ``(B, R, D)``; ``project`` passes it through a
+    2-layer MLP first (``:228,318-319``)."""
+
+    def __init__(self, input_dim, output_dim, num_relation, query_input_dim, message_func="distmult",
+                 aggregate_func="pna", layer_norm=False, activation="relu", project=True):
+        super().__init__()
+        self._init_common(input_dim, output_dim, num_relation, query_input_dim, message_func, aggregate_func,
+                          layer_norm, activation)
+        self.project = project
+        self.relation_projection = MLP(input_dim=query_input_dim, hidden_dims=[input_dim, input_dim])
+        self.relation = None
+
+    def _relation_table(self, graph, batch_size):
+        relation_input = self.relation if isinstance(self.relation, torch.Tensor) else self.relation.weight
+        if self.project:
+            relation_input = self.relation_projection(relation_input)
+        if relation_input.dim() == 2:                          # (R, D) shared by the batch  (layer.py:323-324)
+            return relation_input.unsqueeze(1).expand(-1, batch_size, -1)
+        return relation_input.transpose(1, 0)                  # (B, R, D) -> (R, B, D)      (layer.py:325-326)

@@ -1,0 +1,175 @@
+"""Entity-graph Bellman-Ford network (hot-path caller), mirroring ``/root/reference/ultra/model.py:17-194``.
+
+``TransferNBFNet`` keeps the reference's constructor, attribute names and forward/score API so that the
+``model.*`` entries of ``td_ultra_3g/4g.pth`` load unchanged: ``layers.{i}.linear``,
+``layers.{i}.layer_norm``, ``layers.{i}.relation_projection.layers.{0,1}``, ``mlp.layers.{0,1}``, ``dist_embed``.
+"""
+from collections.abc import Sequence
+
+import torch
+from torch import nn
+
+from . import layer
+from .graph import Graph
+
+
+class TransferNBFNet(nn.Module):
+
+    def __init__(self, input_dim, hidden_dims, num_relation=None, symmetric=False, message_func="distmult",
+                 aggregate_func="pna", short_cut=False, layer_norm=False, activation="relu", concat_hidden=False,
+                 num_mlp_layer=2, project=True, remove_one_hop=False, num_beam=10, path_topk=10, mod=False):
+        super().__init__()
+        if not isinstance(hidden_dims, Sequence):
+            hidden_dims = [hidden_dims]
+        if num_relation is None:
+            double_relation = 1
+        else:
+            num_relation = int(num_relation)
+            double_relation = num_relation * 2
+        self.dims = [input_dim] + list(hidden_dims)
+        self.num_relation = num_relation
+        self.symmetric = symmetric
+        self.short_cut = short_cut
+        self.concat_hidden = concat_hidden
+        self.remove_one_hop = remove_one_hop
+        self.num_beam = num_beam
+        self.path_topk = path_topk
+
+        conv = layer.GeneralizedRelationalConvNBFMod if mod else layer.GeneralizedRelationalConvNBF
+        self.layers = nn.ModuleList(
+            conv(self.dims[i], self.dims[i + 1], double_relation, self.dims[0], message_func, aggregate_func,
+                 layer_norm, activation, project)
+            for i in range(len(self.dims) - 1))
+        feature_dim = hidden_dims[-1] * (len(hidden_dims) if concat_hidden else 1) + input_dim
+        self.query = None
+        self.mlp = layer.MLP(feature_dim, [feature_dim] * (num_mlp_layer - 1) + [1])
+        self.dist_embed = nn.Embedding(10, input_dim)      # model.py:55 (never used in forward)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def remove_easy_edges(self, graph, h_index, t_index, r_index=None):
+        """model.py:57-74: drop the batch's own positive edges (and their reverse when ``remove_one_hop``)."""
+        if self.remove_one_hop:
+            h_ext = torch.cat([h_index, t_index], dim=-1)
+            t_ext = torch.cat([t_index, h_index], dim=-1)
+            cols = [h_ext, t_ext] + ([-torch.ones_like(h_ext)] if r_index is not None else [])
+        else:
+            cols = [h_index, t_index] + ([r_index] if r_index is not None else [])
+        pattern = torch.stack(cols, dim=-1).flatten(0, -2)
+        edge_index = graph.match(pattern)[0]
+        keep = torch.ones(graph.num_edge, dtype=torch.bool, device=graph.device)
+        keep[edge_index] = False
+        return graph.edge_mask(keep)
+
+    def negative_sample_to_tail(self, h_index, t_index, r_index, num_relations):
+        """model.py:76-83: rows that corrupt heads become tail queries of the inverse relation."""
+        is_t_neg = (h_index == h_index[:, [0]]).all(dim=-1, keepdim=True)
+        new_h = torch.where(is_t_neg, h_index, t_index)
+        new_t = torch.where(is_t_neg, t_index, h_index)
+        new_r = torch.where(is_t_neg, r_index, r_index + num_relations)
+        return new_h, new_t, new_r
+
+    def as_relational_graph(self, graph, self_loop=True):
+        """model.py:85-99: homogeneous graph -> one relation (+ self loops)."""
+        edge_list, edge_weight = graph.edge_list[:, :2], graph.edge_weight
+        if self_loop:
+            loop = torch.arange(graph.num_node, device=graph.device)
+            edge_list = torch.cat([edge_list, torch.stack([loop, loop], dim=-1)])
+            edge_weight = torch.cat([edge_weight, torch.ones(graph.num_node, device=graph.device)])
+        relation = torch.zeros(len(edge_list), 1, dtype=torch.long, device=graph.device)
+        return Graph(torch.cat([edge_list, relation], dim=-1), edge_weight, graph.num_node, 1)
+
+    def bellmanford(self, graph, h_index, r_index, separate_grad=False):
+        """model.py:101-143.  Returns ``node_feature`` of shape ``(num_node, batch, feature_dim)``."""
+        bs = h_index.shape[0]
+        if self.query.dim() == 2:
+            query = self.query[r_index]
+        else:
+            query = self.query[torch.arange(bs, device=graph.device), r_index]
+        index = h_index.unsqueeze(-1).expand_as(query)
+        boundary = torch.zeros(graph.num_node, *query.shape, device=query.device)
+        boundary.scatter_add_(0, index.unsqueeze(0), query.unsqueeze(0))
+        graph.query = query
+        graph.boundary = boundary
+
+        hiddens, step_graphs = [], []
+        layer_input = boundary
+        for conv in self.layers:
+            step_graph = graph
+            if separate_grad:
+                step_graph = graph.clone()
+                step_graph.query, step_graph.boundary = query, boundary
+                step_graph.requires_grad = True
+            hidden = conv(step_graph, layer_input)
+            if self.short_cut and hidden.shape == layer_input.shape:
+                hidden = hidden + layer_input
+            hiddens.append(hidden)
+            step_graphs.append(step_graph)
+            layer_input = hidden
+
+        node_query = query.expand(graph.num_node, -1, -1)
+        if self.concat_hidden:
+            output = torch.cat(hiddens + [node_query], dim=-1)
+        else:
+            output = torch.cat([hiddens[-1], node_query], dim=-1)
+        return {"node_feature": output, "step_graphs": step_graphs}
+
+    def forward(self, graph, rel_query_list, h_index, t_index, r_index=None, all_loss=None, metric=None):
+        """model.py:145-194: scores of shape ``h_index.shape``."""
+        if all_loss is not None:
+            graph = self.remove_easy_edges(graph, h_index, t_index, r_index)
+
+        self.query = rel_query_list[0]
+        if len(rel_query_list) > 1:
+            assert len(rel_query_list) == len(self.layers) + 1
+            for i, conv in enumerate(self.layers):
+                conv.relation = rel_query_list[i + 1]
+        else:
+            for conv in self.layers:
+                conv.relation = rel_query_list[0]
+        if metric is not None:
+            q = self.query.detach()
+            metric["query_norm"], metric["query_mean"], metric["query_std"] = q.norm(), q.mean(), q.std()
+
+        shape = h_index.shape
+        if graph.num_relation:
+            num_relations = graph.num_relation
+            graph = self._undirected(graph)
+            h_index, t_index, r_index = self.negative_sample_to_tail(h_index, t_index, r_index, num_relations)
+        else:
+            graph = self.as_relational_graph(graph)
+            h_index = h_index.view(-1, 1)
+            t_index = t_index.view(-1, 1)
+            r_index = torch.zeros_like(h_index)
+
+        assert (h_index[:, [0]] == h_index).all()
+        assert (r_index[:, [0]] == r_index).all()
+        output = self.bellmanford(graph, h_index[:, 0], r_index[:, 0])
+        feature = output["node_feature"].transpose(0, 1)
+        if metric is not None:
+            f = feature.detach()
+            metric["output_norm"], metric["output_mean"], metric["output_std"] = f.norm(), f.mean(), f.std()
+        index = t_index.unsqueeze(-1).expand(-1, -1, feature.shape[-1])
+        feature = feature.gather(1, index)
+
+        if self.symmetric:
+            assert (t_index[:, [0]] == t_index).all()
+            output = self.bellmanford(graph, t_index[:, 0], r_index[:, 0])
+            inv_feature = output["node_feature"].transpose(0, 1)
+            index = h_index.unsqueeze(-1).expand(-1, -1, inv_feature.shape[-1])
+            feature = (feature + inv_feature.gather(1, index)) / 2
+
+        score = self.mlp(feature).squeeze(-1)
+        return score.view(shape)
+
+    def _undirected(self, graph):
+        """``graph.undirected(add_inverse=True)`` (model.py:166), memoised on the graph object: the reference
+        re-materialises (and torchdrug re-sorts) the doubled edge list on every call; evaluation reuses one
+        fact graph for every batch, so the doubled graph and its RelCSR plans are built once."""
+        cached = getattr(graph, "_undirected_inverse", None)
+        if cached is None:
+            cached = graph.undirected(add_inverse=True)
+            graph._undirected_inverse = cached
+        return cached

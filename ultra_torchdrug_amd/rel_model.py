@@ -1,0 +1,159 @@
+"""Relation-graph model (hot-path caller), mirroring ``/root/reference/ultra/rel_model.py``.
+
+* :func:`construct_relation_graph` -- ``rel_model.py:91-181`` for the shipped configuration
+  (``multirelational=True``: 2R relation nodes, 4 edge types hh / tt / ht / th).  One-off preprocessing, done
+  with ATen sparse products exactly as the reference does.
+* :class:`CustomNBFNetFull` -- ``rel_model.py:227-378``: 6 x ``GeneralizedRelationalConvNBF(dependent=False)``
+  with one Bellman-Ford per query relation.
+* :class:`RelNBFNet` -- ``rel_model.py:381-416``; :class:`RelationModelList` -- ``:209-223``.
+
+Parameter names follow the reference (``rel_models.0.model.layers.{i}.{linear,layer_norm,relation}``,
+``rel_models.0.model.mlp.layers.{0,1}``) so checkpoints load unchanged.
+"""
+from collections.abc import Sequence
+
+import torch
+from torch import nn
+
+from . import layer
+from .graph import Graph
+
+
+def construct_relation_graph(graph):
+    """Graph of relations: nodes = 2R relations (with inverses), edge type 0..3 = head-head, tail-tail,
+    head-tail, tail-head co-occurrence of two relations at an entity (``rel_model.py:91-143``)."""
+    graph = graph.undirected(add_inverse=True)
+    device = graph.device
+    n_rel, n_node = graph.num_relation, graph.num_node
+
+    def incidence(col):
+        pairs = graph.edge_list[:, [col, 2]].unique(dim=0)                     # (entity, relation)
+        degree = torch.zeros(n_node, dtype=torch.long, device=device).index_add_(
+            0, pairs[:, 0], torch.ones_like(pairs[:, 1]))
+        assert not (degree[pairs[:, 0]] == 0).any()
+        ones = torch.ones(pairs.shape[0], device=device)
+        normalised_t = torch.sparse_coo_tensor(pairs.flip(1).t(), ones / degree[pairs[:, 0]], (n_rel, n_node))
+        plain = torch.sparse_coo_tensor(pairs.t(), ones, (n_node, n_rel))
+        return normalised_t, plain
+
+    EhT, Eh = incidence(0)
+    EtT, Et = incidence(1)
+    blocks = [torch.sparse.mm(EhT, Eh), torch.sparse.mm(EtT, Et), torch.sparse.mm(EhT, Et), torch.sparse.mm(EtT, Eh)]
+    edges = []
+    for etype, block in enumerate(blocks):
+        idx = block.coalesce().indices().t()
+        edges.append(torch.cat([idx, torch.full((idx.shape[0], 1), etype, dtype=torch.long, device=device)], dim=1))
+    return Graph(torch.cat(edges, dim=0), num_node=n_rel, num_relation=4)
+
+
+class CustomNBFNet(nn.Module):
+    """``rel_model.py:227-339`` (constructor and module tree; the shipped model is the ``Full`` subclass)."""
+
+    def __init__(self, input_dim, hidden_dims, num_relation=None, symmetric=False, message_func="distmult",
+                 aggregate_func="pna", short_cut=False, layer_norm=False, activation="relu", concat_hidden=False,
+                 num_mlp_layer=2, dependent=False, remove_one_hop=False, num_beam=10, path_topk=10,
+                 separate_remove_one_hop=False):
+        super().__init__()
+        if not isinstance(hidden_dims, Sequence):
+            hidden_dims = [hidden_dims]
+        num_relation = 1 if num_relation is None else int(num_relation)
+        self.dims = [input_dim] + list(hidden_dims)
+        self.num_relation = num_relation
+        self.symmetric = symmetric
+        self.short_cut = short_cut
+        self.concat_hidden = concat_hidden
+        self.remove_one_hop = remove_one_hop
+        self.layers = nn.ModuleList(
+            layer.GeneralizedRelationalConvNBF(self.dims[i], self.dims[i + 1], num_relation, self.dims[0],
+                                               message_func, aggregate_func, layer_norm, activation, dependent)
+            for i in range(len(self.dims) - 1))
+        feature_dim = hidden_dims[-1] * (len(hidden_dims) if concat_hidden else 1) + input_dim
+        self.mlp = layer.MLP(feature_dim, [feature_dim] * (num_mlp_layer - 1) + [hidden_dims[-1]])   # unused in forward
+
+    def _run_layers(self, graph, boundary):
+        layer_input = boundary
+        for conv in self.layers:
+            hidden = conv(graph, layer_input)
+            if self.short_cut and hidden.shape == layer_input.shape:
+                hidden = hidden + layer_input
+            layer_input = hidden
+        return layer_input
+
+    def bellmanford(self, graph, h_index, separate_grad=False):
+        """``rel_model.py:268-302``: ONE graph in which all query relations are labelled together."""
+        dev = h_index.device
+        query = torch.ones(h_index.shape[0], self.dims[0], device=dev)
+        boundary = torch.zeros(graph.num_node, query.shape[1], device=dev)
+        boundary[h_index] = 1.0
+        graph.query = query.unsqueeze(0)
+        graph.boundary = boundary.unsqueeze(1)
+        return {"node_feature": self._run_layers(graph, boundary.unsqueeze(1)).squeeze(1)}
+
+    def forward(self, graph, h_index, t_index=None, r_index=None, all_loss=None, metric=None):
+        if not graph.num_relation:
+            relation = torch.zeros(graph.num_edge, 1, dtype=torch.long, device=graph.device)
+            graph = Graph(torch.cat([graph.edge_list[:, :2], relation], dim=-1), graph.edge_weight, graph.num_node, 1)
+        return self.bellmanford(graph, h_index)["node_feature"]
+
+
+class CustomNBFNetFull(CustomNBFNet):
+    """``rel_model.py:343-378``: every query relation gets its own labelled copy -> ``(batch, 2R, dim)``."""
+
+    def __init__(self, learn_query=False, **kwargs):
+        super().__init__(**kwargs)
+        self.learn_query = learn_query
+        if learn_query:
+            self.learnable_q = nn.Embedding(1, self.dims[0])
+
+    def bellmanford(self, graph, h_index, separate_grad=False):
+        dev = h_index.device
+        if self.learn_query:
+            query = self.learnable_q.weight.expand(h_index.shape[0], self.dims[0])
+        else:
+            query = torch.ones(h_index.shape[0], self.dims[0], device=dev)
+        index = h_index.unsqueeze(-1).expand_as(query)
+        boundary = torch.zeros(graph.num_node, *query.shape, device=dev)
+        boundary.scatter_add_(0, index.unsqueeze(0), query.unsqueeze(0))
+        graph.query = query
+        graph.boundary = boundary
+        return {"node_feature": self._run_layers(graph, boundary).transpose(1, 0)}
+
+
+class RelNBFNet(nn.Module):
+    """``rel_model.py:381-416`` (+ the ``RelationModel`` base, ``:54-89``).  ``forward(graph, None, r_idx)``."""
+
+    def __init__(self, input_dim, hidden, num_layers=6, input_type="ones", num_relation=None, **kwargs):
+        super().__init__()
+        self.input_dim = input_dim
+        self.hidden_dim = hidden
+        self.input_type = input_type
+        self.num_relation = num_relation
+        self.ablation_etypes = kwargs.get("ablation_etypes", False)
+        self.model = CustomNBFNetFull(input_dim=input_dim, hidden_dims=[hidden] * num_layers,
+                                      num_relation=4 if not self.ablation_etypes else None, aggregate_func="sum",
+                                      layer_norm=True, short_cut=True, learn_query=kwargs.get("learn_query", False))
+        if self.hidden_dim != self.input_dim:
+            self.input_transform_linear = nn.Linear(self.input_dim, self.hidden_dim)
+
+    def construct_relation_graph(self, graph):
+        return construct_relation_graph(graph)
+
+    def forward(self, graph, input, r_idx, all_loss=None, metric=None):
+        assert input is None                                    # rel_model.py:21
+        x = self.model(graph, h_index=r_idx)
+        return {"graph_feature": None, "node_feature": x}      # (batch, 2R, dim)
+
+
+class RelationModelList(nn.ModuleList):
+    """``rel_model.py:209-223``: ``num_rel_models`` copies built from the ``rel_model`` config dict."""
+
+    def __init__(self, num_rel_models=1, num_relation=None, rel_model=None, **kwargs):
+        super().__init__()
+        self.num_rel_models = num_rel_models
+        self.num_relation = num_relation
+        cfg = dict(rel_model or {})
+        cls = cfg.pop("class_str", "RelNBFNet")
+        if cls != "RelNBFNet":
+            raise ValueError("only RelNBFNet relation models are shipped, got `%s`" % cls)
+        for _ in range(num_rel_models):
+            self.append(RelNBFNet(**cfg, num_relation=num_relation))

@@ -1,0 +1,223 @@
+"""Knowledge-graph-completion task: the caller loop that defines "results" for the hot path.
+
+Mirrors ``/root/reference/ultra/task.py`` for the transductive/inductive single-graph case:
+
+* ``KnowledgeGraphCompletionBase`` ``:22-195``  -- fact-graph split, filter masks (``:65-100``), strict negatives
+  (``:102-118``), BCE + self-adversarial loss (``:160-195``);
+* ``KnowledgeGraphCompletionAdapted`` ``:197-351`` -- relation-graph preparation (``:215-226``), ``predict``
+  (``:228-277``), ``get_ranking`` (``:307-315``), ``evaluate`` (``:317-351``).
+
+Differences, all outside the arithmetic: no torchdrug ``Registry``/``Engine``; graphs are plain attributes
+(not module buffers) so ``state_dict()`` holds exactly the ``model.*`` and ``rel_models.*`` tensors a reference
+checkpoint holds after ``util.clean_save`` (``ultra/util.py:278-325``); scores and masks stay on the device and
+only the int64 ranks leave it (the reference moves ``(B, 2, N)`` scores and masks to the host per batch,
+``task.py:263,295``).
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .graph import Graph
+
+
+def variadic_sample(candidates, sizes, num_sample):
+    """``torchdrug.layers.functional.variadic_sample``: ``num_sample`` draws (with replacement) from each of the
+    variable-length runs of ``candidates`` (``task.py:108,113``)."""
+    rand = torch.rand(len(sizes), num_sample, device=sizes.device)
+    index = (rand * sizes.unsqueeze(-1)).long()
+    index = index + (sizes.cumsum(0) - sizes).unsqueeze(-1)
+    return candidates[index]
+
+
+class KnowledgeGraphCompletion(nn.Module):
+    """``tasks.KnowledgeGraphCompletionAdapted`` with the configuration surface of
+    ``config/transductive/inference.yaml:8-39``."""
+
+    def __init__(self, model, rel_models, criterion="bce",
+                 metric=("mr", "mrr", "hits@1", "hits@3", "hits@10", "mrr-tail", "hits@1-tail", "hits@10-tail"),
+                 num_negative=128, margin=6, adversarial_temperature=0, strict_negative=True, filtered_ranking=True,
+                 fact_ratio=None, sample_weight=False, metric_per_rel=False, full_batch_eval=False):
+        super().__init__()
+        assert strict_negative                                   # task.py:27
+        self.model = model
+        self.rel_models = rel_models
+        self.criterion = {criterion: 1} if isinstance(criterion, str) else dict(criterion)
+        self.metric = tuple(metric)
+        self.num_negative = num_negative
+        self.margin = margin
+        self.adversarial_temperature = adversarial_temperature
+        self.strict_negative = strict_negative
+        self.filtered_ranking = filtered_ranking
+        self.fact_ratio = fact_ratio
+        self.sample_weight = sample_weight
+        self.metric_per_rel = metric_per_rel
+        self.full_batch_eval = full_batch_eval
+        self.graph = self.fact_graph = None
+        self.rel_graphs = []
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    # ------------------------------------------------------------------ preprocessing (task.py:31-63, 215-226)
+    def preprocess(self, graph, fact_mask=None):
+        """``graph``: all triples (train+valid+test) as a :class:`Graph` with (h, t, r) rows; ``fact_mask`` selects
+        the edges message passing may use (train only).  Builds the relation graph(s) from the fact graph."""
+        self.num_entity = graph.num_node
+        self.num_relation = graph.num_relation
+        self.graph = graph
+        self.fact_graph = graph if fact_mask is None else graph.edge_mask(fact_mask)
+        self.rel_graphs = [rel_model.construct_relation_graph(self.fact_graph) for rel_model in self.rel_models]
+        return self
+
+    def to(self, *args, **kwargs):
+        super().to(*args, **kwargs)
+        device = self.device
+        if self.graph is not None:
+            same = self.fact_graph is self.graph
+            self.graph = self.graph.to(device)
+            self.fact_graph = self.graph if same else self.fact_graph.to(device)
+            self.rel_graphs = [g.to(device) for g in self.rel_graphs]
+        return self
+
+    # ------------------------------------------------------------------ filter masks (task.py:65-100)
+    def _calculate_mask(self, graph, anchor_index, pos_r_index, anchor_col):
+        """Boolean ``(B, N)``: False at every entity that completes (anchor, r, ?) / (?, r, anchor) in ``graph``."""
+        any = -torch.ones_like(anchor_index)
+        cols = [anchor_index, any, pos_r_index] if anchor_col == 0 else [any, anchor_index, pos_r_index]
+        pattern = torch.stack(cols, dim=-1)
+        edge_index, num_truth = graph.match(pattern)
+        truth_index = graph.edge_list[edge_index, 1 - anchor_col]
+        pos_index = torch.repeat_interleave(num_truth)
+        mask = torch.ones(len(pattern), graph.num_node, dtype=torch.bool, device=graph.device)
+        mask[pos_index, truth_index] = 0
+        return mask
+
+    def _calculate_t_mask(self, graph, pos_h_index, pos_r_index):
+        return self._calculate_mask(graph, pos_h_index, pos_r_index, 0)
+
+    def _calculate_h_mask(self, graph, pos_t_index, pos_r_index):
+        return self._calculate_mask(graph, pos_t_index, pos_r_index, 1)
+
+    @torch.no_grad()
+    def _strict_negative(self, pos_h_index, pos_t_index, pos_r_index):
+        """task.py:102-118: first half of the batch corrupts tails, second half heads; negatives are non-edges."""
+        half = len(pos_h_index) // 2
+        t_mask = self._calculate_t_mask(self.fact_graph, pos_h_index[:half], pos_r_index[:half])
+        neg_t = variadic_sample(t_mask.nonzero()[:, 1], t_mask.sum(dim=-1), self.num_negative)
+        h_mask = self._calculate_h_mask(self.fact_graph, pos_t_index[half:], pos_r_index[half:])
+        neg_h = variadic_sample(h_mask.nonzero()[:, 1], h_mask.sum(dim=-1), self.num_negative)
+        return torch.cat([neg_t, neg_h])
+
+    # ------------------------------------------------------------------ predict (task.py:228-277)
+    def relation_representations(self, pos_r_index, all_loss=None, metric=None):
+        return [rel_model(rel_graph, None, pos_r_index, all_loss=all_loss, metric=metric)["node_feature"]
+                for rel_model, rel_graph in zip(self.rel_models, self.rel_graphs)]
+
+    def predict(self, batch, all_loss=None, metric=None):
+        pos_h_index, pos_t_index, pos_r_index = batch.t()
+        batch_size = len(batch)
+        rel_inputs = self.relation_representations(pos_r_index, all_loss, metric)
+
+        if all_loss is None:                                                     # evaluation: all entities
+            all_index = torch.arange(self.num_entity, device=batch.device)
+            num_negative = self.num_entity if self.full_batch_eval else self.num_negative
+            t_preds, h_preds = [], []
+            for neg_index in all_index.split(num_negative):
+                r_index = pos_r_index.unsqueeze(-1).expand(-1, len(neg_index))
+                h_index, t_index = torch.meshgrid(pos_h_index, neg_index, indexing="ij")
+                t_preds.append(self.model(self.fact_graph, rel_inputs, h_index, t_index, r_index))
+            for neg_index in all_index.split(num_negative):
+                r_index = pos_r_index.unsqueeze(-1).expand(-1, len(neg_index))
+                t_index, h_index = torch.meshgrid(pos_t_index, neg_index, indexing="ij")
+                h_preds.append(self.model(self.fact_graph, rel_inputs, h_index, t_index, r_index))
+            return torch.stack([torch.cat(t_preds, dim=-1), torch.cat(h_preds, dim=-1)], dim=1)   # (B, 2, N)
+
+        neg_index = self._strict_negative(pos_h_index, pos_t_index, pos_r_index)    # training
+        h_index = pos_h_index.unsqueeze(-1).repeat(1, self.num_negative + 1)
+        t_index = pos_t_index.unsqueeze(-1).repeat(1, self.num_negative + 1)
+        r_index = pos_r_index.unsqueeze(-1).repeat(1, self.num_negative + 1)
+        t_index[:batch_size // 2, 1:] = neg_index[:batch_size // 2]
+        h_index[batch_size // 2:, 1:] = neg_index[batch_size // 2:]
+        return self.model(self.fact_graph, rel_inputs, h_index, t_index, r_index, all_loss=all_loss, metric=metric)
+
+    def target(self, batch):
+        """task.py:279-295: filter masks over the FULL graph and the true tail / head of each triple."""
+        pos_h_index, pos_t_index, pos_r_index = batch.t()
+        t_mask = self._calculate_t_mask(self.graph, pos_h_index, pos_r_index)
+        h_mask = self._calculate_h_mask(self.graph, pos_t_index, pos_r_index)
+        return torch.stack([t_mask, h_mask], dim=1), torch.stack([pos_t_index, pos_h_index], dim=1)
+
+    def get_ranking(self, pred, target):
+        """task.py:307-315: ``sum((pos_pred <= pred) & mask, -1) + 1`` -> int64 ``(B, 2)``."""
+        mask, target = target
+        pos_pred = pred.gather(-1, target.unsqueeze(-1))
+        if self.filtered_ranking:
+            return torch.sum((pos_pred <= pred) & mask, dim=-1) + 1
+        return torch.sum(pos_pred <= pred, dim=-1) + 1
+
+    @torch.no_grad()
+    def rank_batch(self, batch):
+        """Scores, masks and ranks stay on the device; only ``(B, 2)`` int64 ranks are returned."""
+        return self.get_ranking(self.predict(batch), self.target(batch))
+
+    def evaluate(self, ranking):
+        """task.py:317-351 on an int64 ``(n, 2)`` ranking tensor (column 0 = tail, 1 = head)."""
+        metric = {}
+        for name in self.metric:
+            _ranking, _name = ranking, name
+            if "-" in name:
+                _name, direction = name.split("-")
+                if direction not in ("head", "tail"):
+                    raise ValueError("Unknown direction `%s`" % direction)
+                _ranking = ranking.select(1, 1 if direction == "head" else 0)
+            if _name == "mr":
+                score = _ranking.float().mean()
+            elif _name == "mrr":
+                score = (1 / _ranking.float()).mean()
+            elif _name.startswith("hits@"):
+                score = (_ranking <= int(_name[5:])).float().mean()
+            else:
+                raise ValueError("Unknown metric `%s`" % name)
+            metric[name] = score
+        return metric
+
+    # ------------------------------------------------------------------ training loss (task.py:160-195)
+    def forward(self, batch, all_loss=None, metric=None):
+        all_loss = torch.tensor(0, dtype=torch.float32, device=batch.device)
+        metric = {}
+        pred = self.predict(batch, all_loss, metric)
+        for criterion, weight in self.criterion.items():
+            if criterion != "bce":
+                raise ValueError("Unknown criterion `%s`" % criterion)
+            target = torch.zeros_like(pred)
+            target[:, 0] = 1
+            loss = F.binary_cross_entropy_with_logits(pred, target, reduction="none")
+            neg_weight = torch.ones_like(pred)
+            if self.adversarial_temperature > 0:
+                with torch.no_grad():
+                    neg_weight[:, 1:] = F.softmax(pred[:, 1:] / self.adversarial_temperature, dim=-1)
+            else:
+                neg_weight[:, 1:] = 1 / self.num_negative
+            loss = (loss * neg_weight).sum(dim=-1) / neg_weight.sum(dim=-1)
+            loss = loss.mean()
+            metric["binary cross entropy"] = loss
+            all_loss = all_loss + loss * weight
+        return all_loss, metric
+
+
+def build_ultra(num_relation, input_dim=64, hidden_dims=(64,) * 6, rel_hidden=64, rel_layers=6, **task_kwargs):
+    """The shipped architecture: ``config/transductive/inference.yaml:8-39`` (6 x 64d, distmult, sum, shortcut,
+    layer norm, projected relations; relation model 6 x 64d)."""
+    from .model import TransferNBFNet
+    from .rel_model import RelationModelList
+    model = TransferNBFNet(input_dim=input_dim, hidden_dims=list(hidden_dims), num_relation=num_relation,
+                           message_func="distmult", aggregate_func="sum", short_cut=True, layer_norm=True,
+                           project=True, mod=True, remove_one_hop=False)
+    rel_models = RelationModelList(num_rel_models=1, num_relation=2 * num_relation,
+                                   rel_model=dict(class_str="RelNBFNet", input_dim=input_dim, input_type="ones",
+                                                  num_layers=rel_layers, hidden=rel_hidden))
+    defaults = dict(criterion="bce", num_negative=128, strict_negative=True, adversarial_temperature=1.0,
+                    sample_weight=False, full_batch_eval=True)
+    defaults.update(task_kwargs)
+    return KnowledgeGraphCompletion(model, rel_models, **defaults)
