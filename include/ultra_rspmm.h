@@ -70,6 +70,10 @@ typedef struct ultra_segments {
     const int32_t *long_rows;  /* [n_long_rows][3]: {row, first_piece_slot, n_pieces}                   */
     int64_t n_pieces;          /* total piece slots (workspace rows)                                    */
     int64_t piece_len;         /* contributions per piece                                               */
+    /* optional packed edge words for the fast path (NULL when the ids do not fit in 32 bits):           */
+    /*   bits [0,8) row - chunk row_begin | bits [8, src_shift) relation id | bits [src_shift,32) node_a */
+    const uint32_t *packed;
+    int64_t packed_src_shift;
 } ultra_segments;
 
 int ultra_rspmm_abi_version(void);
@@ -87,6 +91,9 @@ int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_ho
  */
 int ultra_rspmm_profile_next(void *start_event, void *stop_event);
 
+/* Test/bench knob: non-zero forces the general kernel even where the packed fast path applies (process-wide). */
+int ultra_rspmm_force_general_path(int on);
+
 /* Scratch bytes a call over `seg` with row width F needs (piece partial sums). */
 size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg_host, int64_t F);
 
@@ -94,6 +101,7 @@ size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg_host, int64_t F);
  * out[v, :] = SUM_{(u, v, r, w) in row v}  w * (relation[r, :] MUL input[u, :])
  * replaces rspmm_{sum}_{mul}_forward_cuda(sparse, relation, input)      [layer.py:134-167,336-369]
  *   fwd       : forward plan;  relation [n_rel, F];  input [n_src, F];  out [fwd->n_rows, F]
+ *   n_src     : rows of `input` (bounds the 32-bit offsets of the packed fast path)
  *   add_rows  : optional [n_rows, F] or NULL.  When given, the epilogue the reference applies right
  *               after the call is fused: sum=add -> out + add_rows (layer.py:156,358),
  *               sum=max -> max(out, add_rows) (layer.py:162,364), sum=min -> min(out, add_rows).
@@ -101,7 +109,7 @@ size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg_host, int64_t F);
  */
 int ultra_rspmm_forward_f32(const ultra_segments *fwd_host, const float *relation, const float *input,
                             const float *add_rows, float *out, void *workspace, size_t workspace_bytes,
-                            int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream);
+                            int64_t n_src, int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream);
 
 /*
  * Gradients of the call above w.r.t. input and relation
@@ -114,8 +122,8 @@ int ultra_rspmm_forward_f32(const ultra_segments *fwd_host, const float *relatio
 int ultra_rspmm_backward_f32(const ultra_segments *by_src_host, const ultra_segments *by_rel_host,
                              const float *relation, const float *input, const float *output,
                              const float *output_grad, float *d_input, float *d_relation, void *workspace,
-                             size_t workspace_bytes, int64_t n_rel, int64_t F, int sum_op, int mul_op,
-                             void *stream);
+                             size_t workspace_bytes, int64_t n_dst, int64_t n_rel, int64_t F, int sum_op,
+                             int mul_op, void *stream);
 
 /*
  * d_weight[e] = sum_f output_grad[dst_e, f] * [out == y] * (relation[r_e, f] MUL input[src_e, f])

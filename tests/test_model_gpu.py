@@ -1,0 +1,96 @@
+"""End-to-end parity on the GPU box: the same seeded random-init Ultra (6 x 64d entity stack + 6 x 64d relation
+stack) on the same seeded synthetic KG, once with the HIP rspmm (cuda:0) and once with the CPU oracle in place of
+the operator (tests/oracle_ops.py).  Everything around the operator (Linear, LayerNorm, score MLP) is the same
+torch code on both sides but runs in rocBLAS/MIOpen on one side and on the host on the other, so scores carry an
+fp32 tolerance (stated below); ranks are compared as integers.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle_ops import oracle_rspmm
+
+pytestmark = pytest.mark.gpu
+
+SCORE_ATOL = 1e-4      # "scores within 1e-4 abs"
+
+
+def _build(shape, seed=1024):
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    triples, n, r = synthetic_triples(shape, seed)
+    graph = Graph(torch.from_numpy(triples), num_node=n, num_relation=r)
+    torch.manual_seed(seed)
+    task = build_ultra(r)
+    task.preprocess(graph)
+    return task.eval(), triples
+
+
+def _near_tie_free(pred, target, mask, margin):
+    """Queries whose positive score is at least `margin` away from every other (unfiltered) candidate score."""
+    pos = pred.gather(-1, target.unsqueeze(-1))
+    gap = (pred - pos).abs()
+    gap.scatter_(-1, target.unsqueeze(-1), float("inf"))
+    gap = torch.where(mask, gap, torch.full_like(gap, float("inf")))
+    return gap.min(dim=-1).values > margin
+
+
+@pytest.mark.parametrize("shape", ["S-tiny", (1200, 9000, 12)])
+def test_predict_scores_and_ranks_match_oracle_path(shape):
+    from ultra_torchdrug_amd.relcsr import PIECE_LEN
+    task, triples = _build(shape)
+    rng = np.random.default_rng(7)
+    batch = torch.from_numpy(triples[rng.choice(len(triples), 16, replace=False)])
+
+    with torch.no_grad(), oracle_rspmm(PIECE_LEN):
+        pred_cpu = task.predict(batch)
+        mask_cpu, target_cpu = task.target(batch)
+        rank_cpu = task.get_ranking(pred_cpu, (mask_cpu, target_cpu))
+
+    dev = torch.device("cuda:0")
+    task.to(dev)
+    with torch.no_grad():
+        pred_gpu = task.predict(batch.to(dev))
+        rank_gpu = task.get_ranking(pred_gpu, task.target(batch.to(dev)))
+    diff = (pred_gpu.cpu() - pred_cpu).abs().max().item()
+    assert diff <= SCORE_ATOL, "scores differ by %.3g" % diff
+    assert torch.equal(task.target(batch.to(dev))[0].cpu(), mask_cpu)
+    # integer ranks: identical wherever the positive is not within 2*diff of another candidate's score
+    safe = _near_tie_free(pred_cpu, target_cpu, mask_cpu, 2 * diff + 1e-7)
+    assert safe.float().mean() > 0.8
+    assert torch.equal(rank_gpu.cpu()[safe], rank_cpu[safe])
+    # and the metric computed from all ranks agrees closely
+    mrr_gpu = (1.0 / rank_gpu.float()).mean().item()
+    mrr_cpu = (1.0 / rank_cpu.float()).mean().item()
+    assert abs(mrr_gpu - mrr_cpu) <= 0.02
+
+
+def test_training_step_gradients_match_oracle_path():
+    """One fine-tuning step's loss and parameter gradients (rspmm fwd+bwd through both stacks)."""
+    from ultra_torchdrug_amd.relcsr import PIECE_LEN
+    task, triples = _build("S-tiny")
+    task.train()
+    task.num_negative = 16
+    batch = torch.from_numpy(triples[:8])
+
+    def run(dev):
+        task.to(dev)
+        task.zero_grad()
+        torch.manual_seed(5)                         # negatives are sampled with torch.rand on `dev`
+        neg = task._strict_negative(*batch.to(dev).t())
+        task._strict_negative = lambda *a: neg.to(a[0].device)
+        loss, _ = task(batch.to(dev))
+        loss.backward()
+        grads = {k: p.grad.detach().cpu().clone() for k, p in task.named_parameters() if p.grad is not None}
+        return loss.item(), grads, neg.cpu()
+
+    with oracle_rspmm(PIECE_LEN):
+        loss_cpu, grads_cpu, neg = run(torch.device("cpu"))
+    task._strict_negative = lambda *a: neg.to(a[0].device)
+    loss_gpu, grads_gpu, _ = run(torch.device("cuda:0"))
+    assert abs(loss_cpu - loss_gpu) <= 1e-5 * max(1.0, abs(loss_cpu))
+    assert grads_cpu.keys() == grads_gpu.keys()
+    for k in grads_cpu:
+        scale = grads_cpu[k].abs().max().item() + 1e-8
+        assert (grads_cpu[k] - grads_gpu[k]).abs().max().item() <= 2e-4 * scale + 1e-6, k

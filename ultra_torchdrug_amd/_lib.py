@@ -30,6 +30,8 @@ class UltraSegments(ctypes.Structure):
         ("long_rows", ctypes.c_void_p),
         ("n_pieces", ctypes.c_int64),
         ("piece_len", ctypes.c_int64),
+        ("packed", ctypes.c_void_p),
+        ("packed_src_shift", ctypes.c_int64),
     ]
 
 
@@ -39,6 +41,7 @@ EXPORTS = (
     "ultra_rspmm_last_hip_error",
     "ultra_rspmm_device_info",
     "ultra_rspmm_profile_next",
+    "ultra_rspmm_force_general_path",
     "ultra_rspmm_workspace_bytes",
     "ultra_rspmm_forward_f32",
     "ultra_rspmm_backward_f32",
@@ -81,12 +84,14 @@ def load():
     lib.ultra_rspmm_device_info.argtypes = [i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.c_char_p, sz]
     lib.ultra_rspmm_profile_next.restype = i32
     lib.ultra_rspmm_profile_next.argtypes = [vp, vp]
+    lib.ultra_rspmm_force_general_path.restype = i32
+    lib.ultra_rspmm_force_general_path.argtypes = [i32]
     lib.ultra_rspmm_workspace_bytes.restype = sz
     lib.ultra_rspmm_workspace_bytes.argtypes = [seg, i64]
     lib.ultra_rspmm_forward_f32.restype = i32
-    lib.ultra_rspmm_forward_f32.argtypes = [seg, vp, vp, vp, vp, vp, sz, i64, i64, i32, i32, vp]
+    lib.ultra_rspmm_forward_f32.argtypes = [seg, vp, vp, vp, vp, vp, sz, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_f32.restype = i32
-    lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i32, i32, vp]
+    lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_weight_f32.restype = i32
     lib.ultra_rspmm_backward_weight_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
     if lib.ultra_rspmm_abi_version() != ABI_VERSION:

@@ -246,6 +246,182 @@ __global__ __launch_bounds__(kBlock) void segment_kernel(const KParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Packed fast path (forward, and d_input for sum=add): same walk, leaner instruction stream.
+// The general kernel above spends ~10 scalar-ALU/branch instructions per edge (three metadata words, a 64-bit
+// row address, a row-change test); the CU issues one scalar instruction per cycle, so that, not memory, bounds
+// it.  Here one 32-bit word per edge carries everything:
+//     bits [0,8)            row - chunk.row_begin   (chunks hold <= 256 rows; pieces: 0)
+//     bits [8, 8+bitsR)     relation id  -> (word & rel_mask) is directly the LDS byte offset rel * 256
+//     bits [src_shift, 32)  gathered node id
+// the gather is a buffer_load_dword with a 32-bit scalar byte offset (node * row_bytes: one s_lshr + one
+// s_mul_i32), and a batch of 8 edges whose last edge is still in the current row skips all row tests.
+struct PParams {
+    const uint32_t *meta;
+    const float *weight;
+    const int4 *chunks;
+    const float *relation;
+    const float *gather;     // forward: input [n_src, F]; d_input: output_grad [n_dst, F]
+    const float *add_rows;
+    float *out;
+    float *partial;
+    long long F;
+    uint32_t gather_bytes;
+    uint32_t row_bytes;
+    uint32_t src_shift;
+    uint32_t rel_mask;       // ((1 << bitsR) - 1) << 8
+    int n_chunks;
+    int n_rel;
+    int n_tiles;
+    int split;
+    int n_slots;
+    int blocks_per_label;
+};
+
+template <int KIND, int SUM, int MUL, bool UNIT_W>
+__global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
+    static_assert(KIND == KIND_FWD || (KIND == KIND_DX && SUM == ULTRA_SUM_ADD), "packed path: forward or sum-backward");
+    constexpr int RED = (KIND == KIND_FWD) ? SUM : ULTRA_SUM_ADD;
+    constexpr bool NEEDS_REL = (KIND == KIND_FWD) || (MUL == ULTRA_MUL_MUL);
+    extern __shared__ __attribute__((aligned(16))) float lds_rel[];
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform(threadIdx.x >> 6);
+    const int label = blockIdx.x % kXcd;
+    const int bl = blockIdx.x / kXcd;
+    const int widx = bl * kWaves + wave;
+    const int nw = p.blocks_per_label * kWaves;
+    const long long F = p.F;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gather), 0, p.gather_bytes, 0x00020000);
+
+    for (int s = label; s < p.n_slots; s += kXcd) {
+        const int tile = s / p.split;
+        const int part = s - tile * p.split;
+        const long long col = (long long)tile * kTile + lane;
+        const bool active = col < F;
+        const uint32_t voff = (uint32_t)((active ? col : F - 1) * 4);
+        if constexpr (NEEDS_REL) {
+            const int total = p.n_rel * kTile;
+            for (int i = threadIdx.x; i < total; i += kBlock) {
+                const int r = i >> 6;
+                const long long c = (long long)tile * kTile + (i & 63);
+                lds_rel[i] = (c < F) ? p.relation[(long long)r * F + c] : 0.0f;
+            }
+            __syncthreads();
+        }
+        const char *lds_lane = reinterpret_cast<const char *>(lds_rel) + lane * 4;
+
+        auto store_row = [&](int r, float v) {
+            if (active) {
+                if constexpr (KIND == KIND_FWD) {
+                    if (p.add_rows != nullptr) v = reduce<RED>(v, p.add_rows[(long long)r * F + col]);
+                }
+                p.out[(long long)r * F + col] = v;
+            }
+        };
+        auto contribute = [&](float acc, float rv, float gv, float w) -> float {
+            if constexpr (KIND == KIND_FWD) {
+                float y = binary<MUL>(rv, gv);
+                if constexpr (!UNIT_W) y = w * y;
+                return reduce<RED>(acc, y);
+            } else {
+                float c = gv;
+                if constexpr (!UNIT_W) c = c * w;
+                if constexpr (MUL == ULTRA_MUL_MUL) c = c * rv;
+                return acc + c;
+            }
+        };
+
+        for (int k = part + p.split * widx; k < p.n_chunks; k += p.split * nw) {
+            const int4 d = p.chunks[uniform(k)];
+            const uint32_t *meta = p.meta + d.x;
+            const float *wts = UNIT_W ? nullptr : p.weight + d.x;
+            const int n = d.y - d.x;
+            const bool is_piece = d.w < 0;
+            const int row_base = d.z;
+            uint32_t cur = 0;
+            float acc = identity<RED>();
+            int e0 = 0;
+            for (; e0 + kUnroll <= n; e0 += kUnroll) {
+                uint32_t m[kUnroll];
+                float wv[kUnroll], gv[kUnroll], rv[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    m[u] = meta[e0 + u];
+                    wv[u] = 1.0f;
+                    if constexpr (!UNIT_W) wv[u] = wts[e0 + u];
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u)
+                    gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    rv[u] = 0.0f;
+                    if constexpr (NEEDS_REL) rv[u] = *reinterpret_cast<const float *>(lds_lane + (m[u] & p.rel_mask));
+                }
+                if ((m[kUnroll - 1] & 0xffu) == cur) {   // whole batch in the current row (always true for pieces)
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) acc = contribute(acc, rv[u], gv[u], wv[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) {
+                        const uint32_t dl = m[u] & 0xffu;
+                        if (dl != cur) {
+                            store_row(row_base + (int)cur, acc);
+                            for (uint32_t q = cur + 1; q < dl; ++q) store_row(row_base + (int)q, identity<RED>());
+                            cur = dl;
+                            acc = identity<RED>();
+                        }
+                        acc = contribute(acc, rv[u], gv[u], wv[u]);
+                    }
+                }
+            }
+            if (e0 < n) {   // tail: fewer than kUnroll edges
+                const int rem = n - e0;
+                uint32_t m[kUnroll];
+                float wv[kUnroll], gv[kUnroll], rv[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int e = e0 + min(u, rem - 1);
+                    m[u] = meta[e];
+                    wv[u] = 1.0f;
+                    if constexpr (!UNIT_W) wv[u] = wts[e];
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u)
+                    gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    rv[u] = 0.0f;
+                    if constexpr (NEEDS_REL) rv[u] = *reinterpret_cast<const float *>(lds_lane + (m[u] & p.rel_mask));
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    if (u < rem) {
+                        const uint32_t dl = m[u] & 0xffu;
+                        if (dl != cur) {
+                            store_row(row_base + (int)cur, acc);
+                            for (uint32_t q = cur + 1; q < dl; ++q) store_row(row_base + (int)q, identity<RED>());
+                            cur = dl;
+                            acc = identity<RED>();
+                        }
+                        acc = contribute(acc, rv[u], gv[u], wv[u]);
+                    }
+                }
+            }
+            if (is_piece) {
+                if (active) p.partial[(long long)(-d.w - 1) * F + col] = acc;
+            } else {
+                store_row(row_base + (int)cur, acc);
+                for (int q = row_base + (int)cur + 1; q < d.w; ++q) store_row(q, identity<RED>());
+            }
+        }
+        if constexpr (NEEDS_REL) __syncthreads();
+    }
+}
+
 // out[row] = epilogue( partial[first] (+) partial[first+1] (+) ... ) in piece order.
 template <int RED>
 __global__ __launch_bounds__(256) void fixup_kernel(const FixParams p) {
@@ -312,6 +488,8 @@ thread_local int g_last_hip_error = 0;
 // one-shot profiling events (ultra_rspmm_profile_next): bracket the next plan's segment kernel on its stream
 thread_local hipEvent_t g_prof_start = nullptr;
 thread_local hipEvent_t g_prof_stop = nullptr;
+// test/bench knob (ultra_rspmm_force_general_path): run the general kernel even where the packed one applies
+bool g_force_general = false;
 
 #define HIP_TRY(expr)                                   \
     do {                                                \
@@ -412,10 +590,50 @@ int check_segments(const ultra_segments *s) {
     return ULTRA_OK;
 }
 
+template <typename Kern, typename Params>
+int launch_with_lds(Kern kern, const Params &p, int grid, size_t lds, hipStream_t stream) {
+    static bool attr_set[16] = {false};   // one table per kernel instantiation
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (lds > 48 * 1024 && dev >= 0 && dev < 16 && !attr_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kMaxLdsBytes));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, p);
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
+template <int KIND, int SUM, int MUL>
+int launch_packed_w(const PParams &p, bool unit_w, int grid, size_t lds, hipStream_t stream) {
+    if (unit_w) return launch_with_lds(packed_kernel<KIND, SUM, MUL, true>, p, grid, lds, stream);
+    return launch_with_lds(packed_kernel<KIND, SUM, MUL, false>, p, grid, lds, stream);
+}
+
+template <int KIND>
+int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, int grid, size_t lds, hipStream_t stream) {
+    if constexpr (KIND == KIND_FWD) {
+#define ULTRA_PCASE(S, M) \
+    if (sum_op == S && mul_op == M) return launch_packed_w<KIND_FWD, S, M>(p, unit_w, grid, lds, stream);
+        ULTRA_PCASE(ULTRA_SUM_ADD, ULTRA_MUL_MUL)
+        ULTRA_PCASE(ULTRA_SUM_ADD, ULTRA_MUL_ADD)
+        ULTRA_PCASE(ULTRA_SUM_MIN, ULTRA_MUL_MUL)
+        ULTRA_PCASE(ULTRA_SUM_MIN, ULTRA_MUL_ADD)
+        ULTRA_PCASE(ULTRA_SUM_MAX, ULTRA_MUL_MUL)
+        ULTRA_PCASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
+#undef ULTRA_PCASE
+    } else if constexpr (KIND == KIND_DX) {
+        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, grid, lds, stream);
+        return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, grid, 0, stream);
+    }
+    return ULTRA_ERR_BAD_OP;
+}
+
 // Runs one plan: segment_kernel over the chunk schedule, then fixup_kernel over the split rows.
 template <int KIND>
-int run_plan(const ultra_segments *seg, KParams p, int64_t n_rel, int64_t F, int sum_op, int mul_op, bool wants_rel_lds,
-             void *workspace, size_t workspace_bytes, hipStream_t stream) {
+int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t n_rel, int64_t F, int sum_op, int mul_op,
+             bool wants_rel_lds, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     int rc = check_segments(seg);
     if (rc) return rc;
     if (F <= 0 || n_rel < 0 || n_rel > 0x7fffffffLL) return ULTRA_ERR_BAD_SHAPE;
@@ -455,8 +673,45 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t n_rel, int64_t F, int
     hipEvent_t ev_start = g_prof_start, ev_stop = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev_start != nullptr) HIP_TRY(hipEventRecord(ev_start, stream));
-    rc = launch_ops<KIND>(p, sum_op, mul_op, seg->weight == nullptr, rel_lds, grid, rel_lds ? lds_need : 0, stream);
-    if (rc) return rc;
+    // packed fast path: forward and sum-backward d_input, when the plan carries packed words, the relation
+    // tile fits LDS and the gathered matrix is addressable with a 32-bit byte offset
+    bool use_packed = false;
+    if constexpr (KIND == KIND_FWD || KIND == KIND_DX) {
+        const float *gather = (KIND == KIND_FWD) ? p.input : p.grad;
+        const unsigned long long gather_bytes = (unsigned long long)gather_rows * (unsigned long long)F * 4ull;
+        use_packed = !g_force_general && seg->packed != nullptr && (KIND == KIND_FWD || sum_op == ULTRA_SUM_ADD) &&
+                     lds_need <= (size_t)kMaxLdsBytes && gather_bytes < 0xffff0000ull && n_rel > 0 &&
+                     (unsigned long long)F * 4ull < 0x7fffffffull;
+        if (use_packed) {
+            PParams q{};
+            q.meta = seg->packed;
+            q.weight = seg->weight;
+            q.chunks = p.chunks;
+            q.relation = p.relation;
+            q.gather = gather;
+            q.add_rows = p.add_rows;
+            q.out = p.out;
+            q.partial = p.partial;
+            q.F = F;
+            q.gather_bytes = (uint32_t)gather_bytes;
+            q.row_bytes = (uint32_t)(F * 4);
+            q.src_shift = (uint32_t)seg->packed_src_shift;
+            q.rel_mask = ((1u << (seg->packed_src_shift - 8)) - 1u) << 8;
+            q.n_chunks = p.n_chunks;
+            q.n_rel = p.n_rel;
+            q.n_tiles = n_tiles;
+            q.split = split;
+            q.n_slots = p.n_slots;
+            q.blocks_per_label = blocks_per_label;
+            const bool needs_rel = (KIND == KIND_FWD) || (mul_op == ULTRA_MUL_MUL);
+            rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, grid, needs_rel ? lds_need : 0, stream);
+            if (rc) return rc;
+        }
+    }
+    if (!use_packed) {
+        rc = launch_ops<KIND>(p, sum_op, mul_op, seg->weight == nullptr, rel_lds, grid, rel_lds ? lds_need : 0, stream);
+        if (rc) return rc;
+    }
     if (ev_stop != nullptr) HIP_TRY(hipEventRecord(ev_stop, stream));
 
     if (seg->n_long_rows > 0) {
@@ -513,6 +768,11 @@ int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_ho
     return ULTRA_OK;
 }
 
+int ultra_rspmm_force_general_path(int on) {
+    g_force_general = on != 0;
+    return ULTRA_OK;
+}
+
 int ultra_rspmm_profile_next(void *start_event, void *stop_event) {
     g_prof_start = static_cast<hipEvent_t>(start_event);
     g_prof_stop = static_cast<hipEvent_t>(stop_event);
@@ -525,8 +785,8 @@ size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg, int64_t F) {
 }
 
 int ultra_rspmm_forward_f32(const ultra_segments *fwd, const float *relation, const float *input, const float *add_rows,
-                            float *out, void *workspace, size_t workspace_bytes, int64_t n_rel, int64_t F, int sum_op,
-                            int mul_op, void *stream) {
+                            float *out, void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_rel, int64_t F,
+                            int sum_op, int mul_op, void *stream) {
     if (fwd == nullptr) return ULTRA_ERR_NULL_POINTER;
     if (fwd->n_rows > 0 && out == nullptr) return ULTRA_ERR_NULL_POINTER;
     if (fwd->n_edges > 0 && (relation == nullptr || input == nullptr)) return ULTRA_ERR_NULL_POINTER;
@@ -535,14 +795,14 @@ int ultra_rspmm_forward_f32(const ultra_segments *fwd, const float *relation, co
     p.input = input;
     p.add_rows = add_rows;
     p.out = out;
-    return run_plan<KIND_FWD>(fwd, p, n_rel, F, sum_op, mul_op, true, workspace, workspace_bytes,
+    return run_plan<KIND_FWD>(fwd, p, n_src, n_rel, F, sum_op, mul_op, true, workspace, workspace_bytes,
                               static_cast<hipStream_t>(stream));
 }
 
 int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments *by_rel, const float *relation,
                              const float *input, const float *output, const float *output_grad, float *d_input,
-                             float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_rel, int64_t F,
-                             int sum_op, int mul_op, void *stream) {
+                             float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_dst, int64_t n_rel,
+                             int64_t F, int sum_op, int mul_op, void *stream) {
     if (output_grad == nullptr || relation == nullptr || input == nullptr) return ULTRA_ERR_NULL_POINTER;
     if (sum_op != ULTRA_SUM_ADD && output == nullptr) return ULTRA_ERR_NULL_POINTER;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -555,7 +815,7 @@ int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments 
         p.grad = output_grad;
         p.out = d_input;
         const bool needs_rel = (mul_op == ULTRA_MUL_MUL) || (sum_op != ULTRA_SUM_ADD);
-        int rc = run_plan<KIND_DX>(by_src, p, n_rel, F, sum_op, mul_op, needs_rel, workspace, workspace_bytes, s);
+        int rc = run_plan<KIND_DX>(by_src, p, n_dst, n_rel, F, sum_op, mul_op, needs_rel, workspace, workspace_bytes, s);
         if (rc) return rc;
     }
     if (d_relation != nullptr) {
@@ -567,7 +827,7 @@ int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments 
         p.output = output;
         p.grad = output_grad;
         p.out = d_relation;
-        int rc = run_plan<KIND_DREL>(by_rel, p, n_rel, F, sum_op, mul_op, false, workspace, workspace_bytes, s);
+        int rc = run_plan<KIND_DREL>(by_rel, p, 0, n_rel, F, sum_op, mul_op, false, workspace, workspace_bytes, s);
         if (rc) return rc;
     }
     return ULTRA_OK;

@@ -103,8 +103,8 @@ def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None):
     with torch.cuda.device(input.device):
         _lib.check(lib.ultra_rspmm_forward_f32(
             seg.pointer, relation.data_ptr(), input.data_ptr(), add_rows.data_ptr() if add_rows is not None else None,
-            out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, csr.shape[2], F, sum_op, mul_op,
-            _stream()))
+            out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, csr.shape[1], csr.shape[2], F, sum_op,
+            mul_op, _stream()))
     return out
 
 
@@ -129,7 +129,7 @@ def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mu
             relation.data_ptr(), input.data_ptr(), output.data_ptr() if output is not None else None,
             output_grad.data_ptr(), d_input.data_ptr() if d_input is not None else None,
             d_relation.data_ptr() if d_relation is not None else None, ws.data_ptr() if ws is not None else None,
-            n_ws * 4, csr.shape[2], F, sum_op, mul_op, _stream()))
+            n_ws * 4, csr.shape[0], csr.shape[2], F, sum_op, mul_op, _stream()))
     return d_input, d_relation
 
 

@@ -54,8 +54,19 @@ class Segments:
         row_ptr = torch.zeros(n_rows + 1, dtype=torch.long, device=dev)
         torch.cumsum(deg, 0, out=row_ptr[1:])
         self.row_ptr = row_ptr
-        chunks, long_rows, n_pieces = _schedule(row_ptr, deg, chunk_edges, chunk_rows, piece_len, balance)
+        chunks, long_rows, n_pieces, row_begin = _schedule(row_ptr, deg, chunk_edges, chunk_rows, piece_len, balance)
         self.chunks = chunks.to(i32).contiguous()
+        # packed edge words for the fast path: row delta | relation << 8 | node_a << src_shift   (ultra_rspmm.h)
+        self.packed, self.packed_src_shift = None, 0
+        n_rel = int(rel.max()) + 1 if n_edges else 1
+        n_a = int(node_a.max()) + 1 if n_edges else 1
+        bits_rel = max((n_rel - 1).bit_length(), 1)
+        if n_edges and chunk_rows <= 256 and 8 + bits_rel + max((n_a - 1).bit_length(), 1) <= 32:
+            delta = row - row_begin[row]
+            word = delta | (rel << 8) | (node_a << (8 + bits_rel))
+            # stored as int32 with the same bit pattern as the unsigned 32-bit word
+            self.packed = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(i32).contiguous()
+            self.packed_src_shift = 8 + bits_rel
         self.long_rows = long_rows.to(i32).contiguous()
         self.n_pieces = int(n_pieces)
 
@@ -76,6 +87,8 @@ class Segments:
         s.long_rows = self.long_rows.data_ptr()
         s.n_pieces = self.n_pieces
         s.piece_len = self.piece_len
+        s.packed = self.packed.data_ptr() if self.packed is not None else None
+        s.packed_src_shift = self.packed_src_shift
 
     @property
     def pointer(self):
@@ -87,11 +100,13 @@ class Segments:
 
 
 def _schedule(row_ptr, deg, chunk_edges, chunk_rows, piece_len, balance):
-    """Vectorised chunk schedule.  Returns (chunks [n,4], long_rows [m,3], n_pieces)."""
+    """Vectorised chunk schedule.  Returns (chunks [n,4], long_rows [m,3], n_pieces, row_begin [n_rows]) where
+    row_begin[r] is the first row of the chunk that owns row r (r itself for split rows)."""
     dev = row_ptr.device
     n_rows = deg.shape[0]
     if n_rows == 0:
-        return (torch.zeros(0, 4, dtype=torch.long, device=dev), torch.zeros(0, 3, dtype=torch.long, device=dev), 0)
+        return (torch.zeros(0, 4, dtype=torch.long, device=dev), torch.zeros(0, 3, dtype=torch.long, device=dev), 0,
+                torch.zeros(0, dtype=torch.long, device=dev))
     rows = torch.arange(n_rows, device=dev)
     is_long = deg > piece_len
     blk = torch.div(row_ptr[:-1], chunk_edges, rounding_mode="floor")
@@ -99,6 +114,7 @@ def _schedule(row_ptr, deg, chunk_edges, chunk_rows, piece_len, balance):
     start = torch.ones(n_rows, dtype=torch.bool, device=dev)
     start[1:] = (blk[1:] != blk[:-1]) | (rblk[1:] != rblk[:-1]) | is_long[1:] | is_long[:-1]
     g_first = torch.nonzero(start).flatten()
+    row_begin = g_first[torch.cumsum(start.long(), 0) - 1]
     g_last = torch.cat([g_first[1:], torch.tensor([n_rows], device=dev)])
     g_long = is_long[g_first]
 
@@ -129,7 +145,7 @@ def _schedule(row_ptr, deg, chunk_edges, chunk_rows, piece_len, balance):
                                                                 chunks[:, 3] - chunks[:, 2])
         order = torch.sort(cost, descending=True, stable=True).indices
         chunks = chunks[order]
-    return chunks, long_rows, n_pieces
+    return chunks, long_rows, n_pieces, row_begin
 
 
 def _sum_duplicates(weight, first, count):
