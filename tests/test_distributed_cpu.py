@@ -1,0 +1,96 @@
+"""CPU, world_size = 2, gloo: the N > 1 path of the engine -- query sharding, the int64 rank all-gather, the flat
+gradient all-reduce and the packed metric reduce.  The rspmm operator is played by the CPU oracle (test
+infrastructure); what is under test is everything that crosses ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(seed=3):
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    triples, n, r = synthetic_triples((120, 700, 4), seed)
+    torch.manual_seed(seed)
+    task = build_ultra(r, hidden_dims=(16,) * 2, input_dim=16, rel_hidden=16, rel_layers=2, num_negative=8)
+    task.preprocess(Graph(torch.from_numpy(triples), num_node=n, num_relation=r))
+    return task, torch.from_numpy(triples)
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), OMP_NUM_THREADS="2")
+    torch.set_num_threads(2)
+    from oracle_ops import oracle_rspmm
+    from ultra_torchdrug_amd import engine
+    engine.init_distributed("gloo")
+    assert engine.get_world_size() == world
+    task, triples = _build()
+    test = triples[:37]                                   # odd count: ranks get 19 and 18 queries
+    with oracle_rspmm(0):
+        task.eval()
+        metric, ranking = engine.evaluate(task, test, batch_size=8)
+        # training: each rank its own batch, then ONE flat all-reduce
+        task.train()
+        torch.manual_seed(100 + rank)
+        batch = triples[40 + 8 * rank: 48 + 8 * rank]
+        opt = torch.optim.AdamW(task.parameters(), lr=5e-4)
+        loss, tmetric = engine.train_step(task, opt, batch)
+    grads = torch.cat([p.grad.reshape(-1) for p in task.parameters() if p.grad is not None])
+    gathered = [torch.zeros_like(grads) for _ in range(world)]
+    dist.all_gather(gathered, grads)
+    assert torch.equal(gathered[0], gathered[1])           # after the all-reduce every rank holds the same gradients
+    unused = sorted(k for k, p in task.named_parameters() if p.grad is None)
+    torch.save(dict(ranking=ranking, mrr=metric["mrr"], loss=loss, tloss=tmetric["binary cross entropy"],
+                    unused=unused, grads=grads), os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_evaluate_and_train_step(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(world))
+    assert torch.equal(r0["ranking"], r1["ranking"]) and r0["ranking"].shape == (37, 2)
+
+    # single-process reference of the same evaluation
+    sys.path.insert(0, HERE)
+    from oracle_ops import oracle_rspmm
+    task, triples = _build()
+    task.eval()
+    with torch.no_grad(), oracle_rspmm(0):
+        want = torch.cat([task.rank_batch(triples[:37][i:i + 8]) for i in range(0, 37, 8)])
+    # batches are composed differently (strided shards), scores of a query do not depend on its batch mates
+    assert torch.equal(r0["ranking"], want)
+    assert abs(float(r0["mrr"]) - float((1.0 / want.float()).mean())) < 1e-6
+    # parameters that never get a gradient are exactly the ones the reference needs find_unused_parameters for
+    assert any(k.startswith("model.dist_embed") for k in r0["unused"])
+    assert any(k.startswith("rel_models.0.model.mlp") for k in r0["unused"])
+    assert torch.equal(r0["grads"], r1["grads"]) and torch.isfinite(r0["grads"]).all()
+    assert abs(float(r0["tloss"]) - float(r1["tloss"])) < 1e-7     # packed metric reduce: same mean on both ranks
+
+
+def test_gather_variable_single_process():
+    from ultra_torchdrug_amd import engine
+    x = torch.arange(10).view(5, 2)
+    assert torch.equal(engine.gather_variable(x), x)
+    assert torch.equal(engine.shard_indices(10, 1, 4), torch.tensor([1, 5, 9]))

@@ -1,0 +1,236 @@
+"""CPU: host-side logic of the package -- plan builder, packed words, graph container, operator error behaviour,
+C-ABI exports, state-dict contract, and the model stack run with the oracle in place of the HIP operator."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from graphs import random_graph
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    """libultra_rspmm.so loads without a GPU and exports each function include/ultra_rspmm.h declares."""
+    from ultra_torchdrug_amd import _lib
+    header = open(os.path.join(ROOT, "include", "ultra_rspmm.h")).read()
+    declared = sorted(set(re.findall(r"\b(ultra_rspmm_\w+)\s*\(", header)))
+    assert len(declared) >= 8
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.EXPORTS) == declared
+    assert lib.ultra_rspmm_abi_version() == 1
+    assert lib.ultra_rspmm_status_string(1).decode().startswith("unknown sum/mul")
+    import ctypes
+    assert ctypes.sizeof(_lib.UltraSegments) == 15 * 8          # struct layout of the header
+
+
+def test_operator_rejects_cpu_tensors_and_bad_names():
+    from ultra_torchdrug_amd import RelCSR, generalized_rspmm
+    e = torch.tensor([0, 1])
+    csr = RelCSR(e, e, e * 0, None, 2, 2, 1)
+    rel, x = torch.randn(1, 4), torch.randn(2, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        generalized_rspmm(csr, rel, x)
+    with pytest.raises(ValueError):
+        generalized_rspmm(csr, rel, x, sum="mean")
+    with pytest.raises(ValueError):
+        generalized_rspmm(csr, rel, x, mul="rotate")
+    with pytest.raises(TypeError):
+        generalized_rspmm(torch.zeros(2, 2), rel, x)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ultra_torchdrug_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert "librspmm_oracle" not in text, f
+
+
+# ------------------------------------------------------------------------------------------------ plans
+@pytest.mark.parametrize("kw", [dict(n_edge=4000, skew=True, hub_row=7, hub_edges=900, isolated=40),
+                                dict(n_edge=300, weights=True), dict(n_edge=0)])
+def test_relcsr_matches_oracle_coalesce_and_covers_everything(oracle, kw):
+    from ultra_torchdrug_amd import RelCSR
+    n, r = 250, 9
+    g = random_graph(seed=1, n_node=n, n_rel=r, **kw)
+    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), None if g["w"] is None else _t(g["w"]), n, n, r,
+                 chunk_edges=16, piece_len=32)
+    ref = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    assert csr.n_edges == ref.n_edges
+    assert np.array_equal(csr.dst.numpy(), ref.row) and np.array_equal(csr.src.numpy(), ref.col)
+    assert np.array_equal(csr.rel_id.numpy(), ref.rel)
+    if ref.n_edges:
+        assert np.array_equal(csr.weight.numpy(), ref.w)
+    for seg, n_rows in ((csr.fwd, n), (csr.by_src, n), (csr.by_rel, r)):
+        rows = seg.row.numpy()
+        assert (np.diff(rows) >= 0).all()
+        ch = seg.chunks.numpy().astype(np.int64)
+        edge_cov, row_cov = np.zeros(seg.n_edges, int), np.zeros(n_rows, int)
+        slots = []
+        for a, b, r0, r1 in ch:
+            edge_cov[a:b] += 1
+            if r1 >= 0:
+                row_cov[r0:r1] += 1
+                assert r1 - r0 <= 64 and set(rows[a:b]) <= set(range(r0, r1))
+            else:
+                assert b - a <= 32 and (rows[a:b] == r0).all()
+                slots.append(-r1 - 1)
+        assert (edge_cov == 1).all()
+        lr = seg.long_rows.numpy()
+        row_cov[lr[:, 0]] += 1
+        assert (row_cov == 1).all()                                   # every row written exactly once
+        assert sorted(slots) == list(range(seg.n_pieces))
+        deg = np.bincount(rows, minlength=n_rows)
+        assert set(lr[:, 0]) == set(np.nonzero(deg > 32)[0])
+        assert (lr[:, 2] == -(-deg[lr[:, 0]] // 32)).all()
+        if seg.packed is not None:                                    # packed words decode to the plain arrays
+            w = seg.packed.numpy().astype(np.int64)[:seg.n_edges] & 0xFFFFFFFF
+            sh = seg.packed_src_shift
+            assert np.array_equal(w >> sh, seg.node_a.numpy())
+            assert np.array_equal((w >> 8) & ((1 << (sh - 8)) - 1), seg.rel.numpy())
+            begin = np.zeros(seg.n_edges, int)
+            for a, b, r0, r1 in ch:
+                begin[a:b] = r0
+            assert np.array_equal(w & 0xFF, rows - begin)
+
+
+def test_schedule_emulation_reproduces_the_oracle_in_kernel_order(oracle):
+    """Walk the fwd plan exactly as the kernels do (numpy fp32, chunk by chunk, pieces + fix-up) and compare with
+    oracle.rspmm_forward(piece=...): pins the meaning of the schedule on the CPU."""
+    from ultra_torchdrug_amd import RelCSR
+    n, r, F, piece = 90, 4, 6, 16
+    g = random_graph(seed=9, n_node=n, n_edge=1500, n_rel=r, skew=True, unique=True, weights=True, isolated=7)
+    rng = np.random.default_rng(0)
+    relation = rng.standard_normal((r, F)).astype(np.float32); x = rng.standard_normal((n, F)).astype(np.float32)
+    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), _t(g["w"]), n, n, r, chunk_edges=8, piece_len=piece)
+    seg = csr.fwd
+    row, a_, rel_, w_ = seg.row.numpy(), seg.node_a.numpy(), seg.rel.numpy(), seg.weight.numpy()
+    out = np.full((n, F), np.nan, dtype=np.float32)
+    partial = np.zeros((seg.n_pieces, F), dtype=np.float32)
+    for e0, e1, r0, r1 in seg.chunks.numpy():
+        if r1 < 0:
+            acc = np.zeros(F, dtype=np.float32)
+            for e in range(e0, e1):
+                acc = acc + w_[e] * (relation[rel_[e]] * x[a_[e]])
+            partial[-r1 - 1] = acc
+        else:
+            out[r0:r1] = 0
+            for e in range(e0, e1):
+                out[row[e]] = out[row[e]] + w_[e] * (relation[rel_[e]] * x[a_[e]])
+    for rr, first, cnt in seg.long_rows.numpy():
+        acc = np.zeros(F, dtype=np.float32)
+        for k in range(cnt):
+            acc = acc + partial[first + k]
+        out[rr] = acc
+    ref = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    assert np.array_equal(out, oracle.rspmm_forward(ref, relation, x, "add", "mul", piece=piece))
+
+
+# ------------------------------------------------------------------------------------------------ graph
+def test_graph_undirected_match_edge_mask():
+    from ultra_torchdrug_amd.graph import Graph
+    rng = np.random.default_rng(0)
+    edges = np.stack([rng.integers(0, 30, 200), rng.integers(0, 30, 200), rng.integers(0, 4, 200)], 1)
+    g = Graph(_t(edges), num_node=30, num_relation=4)
+    u = g.undirected(add_inverse=True)
+    assert u.num_edge == 400 and u.num_relation == 8
+    assert torch.equal(u.edge_list[0::2], g.edge_list)
+    assert torch.equal(u.edge_list[1::2, 0], g.edge_list[:, 1]) and torch.equal(u.edge_list[1::2, 2], g.edge_list[:, 2] + 4)
+    pattern = torch.tensor([[edges[0, 0], -1, edges[0, 2]], [-1, edges[5, 1], -1], [3, 3, 3], [-1, -1, -1]])
+    idx, num = g.match(pattern)
+    off = 0
+    for p, k in zip(pattern.tolist(), num.tolist()):
+        want = [i for i, e in enumerate(edges.tolist()) if all(q < 0 or q == v for q, v in zip(p, e))]
+        assert sorted(idx[off:off + k].tolist()) == want
+        off += k
+    keep = torch.ones(200, dtype=torch.bool); keep[idx[:num[0]]] = False
+    assert g.edge_mask(keep).num_edge == 200 - int(num[0])
+    deg = torch.zeros(30).index_add_(0, g.edge_list[:, 1], torch.ones(200))
+    assert torch.equal(g.degree_out, deg)
+    assert g.adjacency.shape == (30, 30, 4)
+
+
+# ------------------------------------------------------------------------------------------------ model stack
+def test_state_dict_contract():
+    """Key names / shapes of SURVEY.md 8b (td_ultra_3g/4g checkpoints load with strict=True on these keys)."""
+    from ultra_torchdrug_amd.task import build_ultra
+    task = build_ultra(237)
+    sd = task.state_dict()
+    want = {"model.dist_embed.weight": (10, 64), "model.mlp.layers.0.weight": (128, 128), "model.mlp.layers.0.bias": (128,),
+            "model.mlp.layers.1.weight": (1, 128), "model.mlp.layers.1.bias": (1,),
+            "rel_models.0.model.mlp.layers.0.weight": (128, 128), "rel_models.0.model.mlp.layers.0.bias": (128,),
+            "rel_models.0.model.mlp.layers.1.weight": (64, 128), "rel_models.0.model.mlp.layers.1.bias": (64,)}
+    for i in range(6):
+        p = "model.layers.%d." % i
+        want.update({p + "linear.weight": (64, 128), p + "linear.bias": (64,), p + "layer_norm.weight": (64,),
+                     p + "layer_norm.bias": (64,), p + "relation_projection.layers.0.weight": (64, 64),
+                     p + "relation_projection.layers.0.bias": (64,), p + "relation_projection.layers.1.weight": (64, 64),
+                     p + "relation_projection.layers.1.bias": (64,)})
+        q = "rel_models.0.model.layers.%d." % i
+        want.update({q + "linear.weight": (64, 128), q + "linear.bias": (64,), q + "layer_norm.weight": (64,),
+                     q + "layer_norm.bias": (64,), q + "relation.weight": (4, 64)})
+    assert {k: tuple(v.shape) for k, v in sd.items()} == want
+    assert sum(v.numel() for v in sd.values()) == 194113
+    task.load_state_dict({k: torch.zeros(s) for k, s in want.items()}, strict=True)
+
+
+def test_rspmm_path_equals_materialised_path_in_the_layers():
+    """ultra/layer.py:111-113 vs :298-384: the O(E) message/aggregate definition (graph.requires_grad) and the
+    rspmm branch must give the same layer output.  rspmm is played by the CPU oracle here (no GPU)."""
+    from oracle_ops import oracle_rspmm
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd import layer
+    triples, n, r = synthetic_triples("S-tiny")
+    graph = Graph(_t(triples), num_node=n, num_relation=r).undirected(add_inverse=True)
+    torch.manual_seed(0)
+    B, D = 3, 16
+    for agg in ("sum", "mean", "max", "pna"):
+        for msg in ("distmult", "transe"):
+            if (agg, msg) == ("pna", "transe"):
+                # the reference's rspmm branch squares the OPERANDS (layer.py:367: relation ** 2, input ** 2) which
+                # equals the squared message only for distmult; mirrored faithfully, so the two branches differ here
+                continue
+            conv = layer.GeneralizedRelationalConvNBFMod(D, D, 2 * r, D, msg, agg, layer_norm=True)
+            conv.relation = torch.randn(B, 2 * r, D)
+            graph.query = torch.randn(B, D)
+            graph.boundary = torch.zeros(n, B, D); graph.boundary[5] = graph.query
+            x = torch.randn(n, B, D)
+            with torch.no_grad(), oracle_rspmm(0):
+                graph.requires_grad = False
+                fast = conv(graph, x)
+            with torch.no_grad():
+                graph.requires_grad = True
+                slow = conv(graph, x)
+            graph.requires_grad = False
+            torch.testing.assert_close(fast, slow, rtol=2e-4, atol=2e-4)
+
+
+def test_relation_graph_construction():
+    """ultra/rel_model.py:91-143 on a 3-triple toy graph, checked by brute force."""
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.rel_model import construct_relation_graph
+    g = Graph(torch.tensor([[0, 1, 0], [1, 2, 1], [0, 2, 1]]), num_node=3, num_relation=2)
+    rg = construct_relation_graph(g)
+    assert rg.num_node == 4 and rg.num_relation == 4
+    und = g.undirected(add_inverse=True).edge_list.tolist()
+    heads = {(h, r) for h, t, r in und}; tails = {(t, r) for h, t, r in und}
+    want = set()
+    for etype, (A, B) in enumerate([(heads, heads), (tails, tails), (heads, tails), (tails, heads)]):
+        for (e1, r1) in A:
+            for (e2, r2) in B:
+                if e1 == e2:
+                    want.add((r1, r2, etype))
+    assert set(map(tuple, rg.edge_list.tolist())) == want

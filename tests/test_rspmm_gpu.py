@@ -230,3 +230,54 @@ def test_fb15k237_shape_properties(oracle):
     from ultra_torchdrug_amd.relcsr import PIECE_LEN
     want = oracle.rspmm_forward(csr_o, relation[:, :64].cpu().numpy(), x1[:, :64].cpu().numpy(), piece=PIECE_LEN)
     assert np.array_equal(o1[:, :64].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_committed_golden_vectors(general):
+    """HIP library against tests/golden/rspmm_seeded.npz (bit for bit), on the packed fast path and with the
+    general kernel forced (ultra_rspmm_force_general_path)."""
+    import os
+    import ultra_torchdrug_amd as U
+    from ultra_torchdrug_amd import functional as UF
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rspmm_seeded.npz"))
+    n, r, piece = int(z["n_node"]), int(z["n_rel"]), int(z["piece"])
+    dev = _dev()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    lib = U.require_library()
+    lib.ultra_rspmm_force_general_path(1 if general else 0)
+    try:
+        csr = U.RelCSR(t(z["dst"]), t(z["src"]), t(z["rel"]), t(z["w"]), n, n, r, piece_len=piece)
+        for s in SUMS:
+            for m in MULS:
+                rel_t, x_t = t(z["relation"]).requires_grad_(), t(z["x"]).requires_grad_()
+                out = UF.generalized_rspmm(csr, rel_t, x_t, sum=s, mul=m)
+                out.backward(t(z["grad"]))
+                assert _same(out.detach().cpu().numpy(), z["fwd_%s_%s" % (s, m)]), (s, m)
+                assert _same(x_t.grad.cpu().numpy(), z["dx_%s_%s" % (s, m)]), (s, m)
+                assert _same(rel_t.grad.cpu().numpy(), z["drel_%s_%s" % (s, m)]), (s, m)
+    finally:
+        lib.ultra_rspmm_force_general_path(0)
+
+
+@pytest.mark.parametrize("case", ["skewed_hub", "small_weights"])
+def test_general_kernel_equals_packed_kernel(oracle, case):
+    """Both forward kernels implement one summation order: identical output."""
+    import ultra_torchdrug_amd as U
+    from ultra_torchdrug_amd import functional as UF
+    kw, n, r, F = CASES[case]
+    g = random_graph(seed=77, n_node=n, n_rel=r, **kw)
+    relation, x = _inputs(6, n, r, F)
+    dev = _dev()
+    csr = _relcsr(g, n, n, r)
+    assert csr.fwd.packed is not None
+    lib = U.require_library()
+    outs = []
+    for general in (0, 1):
+        lib.ultra_rspmm_force_general_path(general)
+        try:
+            outs.append([UF.rspmm_forward(csr, torch.from_numpy(relation).to(dev), torch.from_numpy(x).to(dev), s, m)
+                         for s in SUMS for m in MULS])
+        finally:
+            lib.ultra_rspmm_force_general_path(0)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -1,0 +1,71 @@
+"""Kernel micro-benchmark: one rspmm forward (add, mul) on a benchmark-shaped graph, HIP-event timed.
+
+    ULTRA_RSPMM_LIB=/path/to/variant.so python tools/kbench.py [--workload S-fb15k237] [--batch 16] [--reps 50]
+
+Used to A/B kernel variants (built with different -D flags) in one gpurun call; prints one line per run.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="S-fb15k237")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--piece", type=int, default=None)
+    ap.add_argument("--chunk", type=int, default=None)
+    ap.add_argument("--general", action="store_true")
+    ap.add_argument("--backward", action="store_true")
+    args = ap.parse_args()
+    import ultra_torchdrug_amd as U
+    from ultra_torchdrug_amd import _lib, relcsr, functional as UF
+    from ultra_torchdrug_amd.data import synthetic_kg
+    if args.piece:
+        relcsr.PIECE_LEN = args.piece
+    if args.chunk:
+        relcsr.CHUNK_EDGES = args.chunk
+    lib = U.require_library()
+    lib.ultra_rspmm_force_general_path(1 if args.general else 0)
+    dev = torch.device("cuda:0")
+    g = synthetic_kg(args.workload, device=dev).undirected(add_inverse=True)
+    opts = dict(piece_len=relcsr.PIECE_LEN, chunk_edges=relcsr.CHUNK_EDGES)
+    csr = U.RelCSR.from_edge_list(g.edge_list, g.edge_weight, g.num_node, g.num_relation, **opts)
+    F = args.batch * 64
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    relation = torch.randn(g.num_relation, F, generator=gen).to(dev)
+    x = torch.randn(g.num_node, F, generator=gen).to(dev)
+    grad = torch.randn(g.num_node, F, generator=gen).to(dev)
+
+    def run():
+        if args.backward:
+            return UF.rspmm_backward(csr, relation, x, None, grad, "add", "mul")
+        return UF.rspmm_forward(csr, relation, x, "add", "mul")
+
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(args.reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        run()
+        b.record()
+        torch.cuda.synchronize()
+        times.append(a.elapsed_time(b) * 1e3)
+    times = np.array(times)
+    E = csr.n_edges
+    algo = E * (4 * F + 12) + 4 * g.num_node * F + 4 * g.num_relation * F
+    print("%s lib=%s %s B=%d E=%d chunks=%d pieces=%d: median %.1f us  min %.1f us  (%.2f TB/s algorithmic, %.2e edge-msgs/s)"
+          % (args.workload, os.path.basename(_lib.LIB_PATH), "bwd" if args.backward else "fwd", args.batch, E,
+             csr.fwd.chunks.shape[0], csr.fwd.n_pieces, np.median(times), times.min(), algo / np.median(times) / 1e6,
+             E * args.batch / (np.median(times) * 1e-6)))
+
+
+if __name__ == "__main__":
+    main()

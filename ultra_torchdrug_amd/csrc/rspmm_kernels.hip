@@ -31,7 +31,10 @@ namespace {
 constexpr int kTile = 64;            // columns per tile == wave width
 constexpr int kBlock = 1024;         // threads per workgroup (16 waves, 4 per SIMD)
 constexpr int kWaves = kBlock / 64;
-constexpr int kUnroll = 8;           // gathers in flight per wave
+#ifndef ULTRA_UNROLL
+#define ULTRA_UNROLL 8
+#endif
+constexpr int kUnroll = ULTRA_UNROLL;   // gathers in flight per wave
 constexpr int kXcd = 8;
 constexpr int kFixUnroll = 16;
 constexpr int kMaxLdsBytes = 156 * 1024;   // leave a little of the 160 KiB

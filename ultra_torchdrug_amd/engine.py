@@ -1,0 +1,125 @@
+"""Query-sharded multi-GPU driver for the hot path (one process per GPU, ``torch.distributed``).
+
+The path shards over QUERIES only: every rank holds the whole graph and the 0.78 MB of weights and runs
+Bellman-Ford for its own batch elements; there is no exchange inside rspmm.  What crosses ranks:
+
+* evaluation -- one ``all_gather`` of the int64 ``(n_local, 2)`` rankings at the end (the reference gathers the
+  full ``(n, 2, N)`` score tensors through gloo: ``/root/reference/ultra/engine.py:146-151``);
+* training -- ONE all-reduce of a flat fp32 gradient buffer per step (the reference: DDP with
+  ``find_unused_parameters=True``, ``ultra/engine.py:55-60``; parameters that never receive a gradient --
+  ``model.dist_embed``, the relation model's ``mlp`` -- are simply absent from the buffer), plus one packed
+  all-reduce for the metric scalars (``ultra/engine.py:90``).
+
+Backend: ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` on CPU (tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (set by ``torch.distributed.run``)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 or dist.is_initialized():
+        return get_rank(), get_world_size()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend)
+    return get_rank(), get_world_size()
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shard_indices(n, rank=None, world=None):
+    """Strided shard ``rank, rank + world, ...`` of ``range(n)`` (DistributedSampler order, no padding)."""
+    rank = get_rank() if rank is None else rank
+    world = get_world_size() if world is None else world
+    return torch.arange(rank, n, world)
+
+
+def gather_variable(local):
+    """All-gather tensors whose first dimension differs per rank; returns them re-interleaved in the strided
+    order of :func:`shard_indices`, i.e. in the original global order."""
+    world = get_world_size()
+    if world == 1:
+        return local
+    n_local = torch.tensor([local.shape[0]], dtype=torch.long, device=local.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    sizes = [int(s.item()) for s in sizes]
+    pad = max(sizes)
+    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[:local.shape[0]] = local
+    parts = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    total = sum(sizes)
+    out = torch.zeros((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r, (part, size) in enumerate(zip(parts, sizes)):
+        out[r:total:world][:size] = part[:size]
+    return out
+
+
+@torch.no_grad()
+def evaluate(task, triples, batch_size=16):
+    """Filtered ranking of ``triples`` ((n, 3) rows of (h, t, r)) sharded over ranks; every rank returns the
+    metrics of the WHOLE set.  Only int64 ranks cross ranks."""
+    device = task.device
+    mine = shard_indices(len(triples))
+    local = triples[mine].to(device)
+    ranks = [task.rank_batch(local[i:i + batch_size]) for i in range(0, len(local), batch_size)]
+    ranks = torch.cat(ranks) if ranks else torch.zeros(0, 2, dtype=torch.long, device=device)
+    ranking = gather_variable(ranks)
+    return task.evaluate(ranking), ranking
+
+
+def allreduce_gradients(module, average=True):
+    """One flat all-reduce over every parameter that has a gradient on this step.  Which parameters have one is
+    a static property of the architecture, so all ranks build the same buffer."""
+    world = get_world_size()
+    params = [p for p in module.parameters() if p.grad is not None]
+    if world == 1 or not params:
+        return 0
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat)
+    if average:
+        flat /= world
+    offset = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[offset:offset + n].view_as(p.grad))
+        offset += n
+    return flat.numel()
+
+
+def reduce_metrics(metric):
+    """Mean over ranks of a dict of 0-d tensors, in one packed all-reduce (``ultra/engine.py:90``)."""
+    world = get_world_size()
+    if world == 1 or not metric:
+        return metric
+    keys = sorted(metric)
+    packed = torch.stack([metric[k].detach().float().reshape(()) for k in keys])
+    dist.all_reduce(packed)
+    packed /= world
+    return {k: packed[i] for i, k in enumerate(keys)}
+
+
+def train_step(task, optimizer, batch):
+    """One fine-tuning step (``ultra/engine.py:62-92`` / torchdrug ``Engine.train``): forward, backward,
+    gradient all-reduce, optimizer step.  Returns (loss, metrics averaged over ranks)."""
+    loss, metric = task(batch)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    allreduce_gradients(task)
+    optimizer.step()
+    return loss.detach(), reduce_metrics(metric)

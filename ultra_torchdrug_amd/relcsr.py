@@ -30,6 +30,7 @@ from . import _lib
 CHUNK_EDGES = 64     # target edges per whole-row chunk
 CHUNK_ROWS = 64      # at most this many rows per chunk (bounds the work of runs of empty rows)
 PIECE_LEN = 128      # rows longer than this are cut into pieces of this many edges
+PACK_SLACK = 16      # readable words after the last edge of `packed` / `weight` (whole-batch loads)
 _INT32_MAX = 2 ** 31 - 1
 
 
@@ -48,7 +49,8 @@ class Segments:
         self.node_a = node_a.to(i32).contiguous()
         self.node_b = None if node_b is None else node_b.to(i32).contiguous()
         self.rel = rel.to(i32).contiguous()
-        self.weight = None if weight is None else weight.to(torch.float32).contiguous()
+        self.weight = None if weight is None else torch.cat(
+            [weight.to(torch.float32), torch.ones(PACK_SLACK, dtype=torch.float32, device=dev)]).contiguous()
 
         deg = torch.bincount(row, minlength=n_rows) if n_edges else torch.zeros(n_rows, dtype=torch.long, device=dev)
         row_ptr = torch.zeros(n_rows + 1, dtype=torch.long, device=dev)
@@ -65,7 +67,9 @@ class Segments:
             delta = row - row_begin[row]
             word = delta | (rel << 8) | (node_a << (8 + bits_rel))
             # stored as int32 with the same bit pattern as the unsigned 32-bit word
-            self.packed = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(i32).contiguous()
+            word = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(i32)
+            # PACK_SLACK zero words after the last edge: the kernel always loads whole batches of 8 words
+            self.packed = torch.cat([word, torch.zeros(PACK_SLACK, dtype=i32, device=dev)]).contiguous()
             self.packed_src_shift = 8 + bits_rel
         self.long_rows = long_rows.to(i32).contiguous()
         self.n_pieces = int(n_pieces)
