@@ -1,0 +1,109 @@
+// Micro-benchmark: how fast can one CU gather 256-B row segments from an L2-resident table, by load shape?
+//   A: buffer_load_dword   64 lanes x 4 B  = 1 row  per wave-instruction   (what the rspmm kernels do today)
+//   B: buffer_load_dwordx4 64 lanes x 16 B = 4 rows per wave-instruction   (registers)
+//   C: global_load_lds_dwordx4             = 4 rows per wave-instruction   (LDS-DMA, then ds_read_b32 per row)
+// build: hipcc -O3 --offload-arch=gfx950 -o gather tools/ubench/gather.hip ; run: ./gather
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+constexpr int kRows = 14541;          // table rows (FB15k237 nodes)
+constexpr int kRowStride = 1024;      // floats per row (F); we gather one 64-float tile of it
+constexpr int kBlock = 1024;
+constexpr int kPerWave = 4096;        // rows gathered per wave
+
+__global__ __launch_bounds__(kBlock) void gather_a(const float* tab, const int* idx, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const int* my = idx + (size_t)wave * kPerWave;
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, kRows * kRowStride * 4, 0x00020000);
+    float acc = 0;
+    for (int i = 0; i < kPerWave; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, my[i + u] * (kRowStride * 4), 0));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    out[(size_t)wave * 64 + lane] = acc;
+}
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kBlock) void gather_b(const float* tab, const int* idx, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const int* my = idx + (size_t)wave * kPerWave;
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, kRows * kRowStride * 4, 0x00020000);
+    float acc = 0;
+    for (int i = 0; i < kPerWave; i += 32) {
+        uint4v v[8];
+        const int mine = my[i + (lane & 31)];   // one vector load of 32 indices
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = __shfl(mine, u * 4 + q, 64);
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, row * (kRowStride * 4) + j * 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += __builtin_bit_cast(float, v[u].x) + __builtin_bit_cast(float, v[u].y) + __builtin_bit_cast(float, v[u].z) + __builtin_bit_cast(float, v[u].w);
+    }
+    out[(size_t)wave * 64 + lane] = acc;
+}
+
+// LDS-DMA: each wave owns 2 KiB of LDS (two 1-KiB slots = 8 rows in flight), rows land as [4 rows][64 floats]
+__global__ __launch_bounds__(kBlock) void gather_c(const float* tab, const int* idx, float* out) {
+    __shared__ __attribute__((aligned(16))) float stage[16 * 512];
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, j = lane & 15;
+    const int wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const int* my = idx + (size_t)wave * kPerWave;
+    float* slot = stage + wl * 512;
+    float acc = 0;
+    for (int i = 0; i < kPerWave; i += 32) {
+        const int mine = my[i + (lane & 31)];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            const int row0 = __shfl(mine, u * 4 + q, 64);
+            const int row1 = __shfl(mine, u * 4 + 4 + q, 64);
+            __builtin_amdgcn_global_load_lds(tab + (size_t)row0 * kRowStride + j * 4, (__attribute__((address_space(3))) void*)(slot), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(tab + (size_t)row1 * kRowStride + j * 4, (__attribute__((address_space(3))) void*)(slot + 256), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += slot[k * 64 + lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    out[(size_t)wave * 64 + lane] = acc;
+}
+
+int main() {
+    int n_cu = 256;
+    const int blocks = n_cu, waves = blocks * 16;
+    std::vector<int> h((size_t)waves * kPerWave);
+    srand(1);
+    for (auto& v : h) v = rand() % kRows;
+    float *tab, *out; int* idx;
+    hipMalloc(&tab, (size_t)kRows * kRowStride * 4);
+    hipMemset(tab, 0, (size_t)kRows * kRowStride * 4);
+    hipMalloc(&out, (size_t)waves * 64 * 4);
+    hipMalloc(&idx, h.size() * 4);
+    hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const double bytes = (double)waves * kPerWave * 256;
+    for (int which = 0; which < 3; ++which) {
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(a);
+            if (which == 0) hipLaunchKernelGGL(gather_a, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
+            if (which == 1) hipLaunchKernelGGL(gather_b, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
+            if (which == 2) hipLaunchKernelGGL(gather_c, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (rep == 2) printf("variant %c: %.3f ms  %.2f TB/s  %.1f GB/s/CU (%s)\n", 'A' + which, ms, bytes / ms / 1e9, bytes / ms / 1e6 / n_cu, hipGetErrorString(hipGetLastError()));
+        }
+    }
+    return 0;
+}

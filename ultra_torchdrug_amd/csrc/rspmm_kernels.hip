@@ -239,7 +239,11 @@ __global__ __launch_bounds__(kBlock) void segment_kernel(const KParams p) {
             }
             __syncthreads();
         }
-        for (int k = part + p.split * widx; k < p.n_chunks; k += p.split * nw) {
+        // chunks are sorted heaviest first; dealing them in serpentine order (0..nw-1, nw-1..0, ...) gives every
+        // wavefront a near-equal share (round-robin would hand wave 0 the heaviest chunk of every round)
+        for (int t = 0;; ++t) {
+            const int k = part + p.split * (t * nw + ((t & 1) ? (nw - 1 - widx) : widx));
+            if (k >= p.n_chunks) break;
             const int4 d = p.chunks[uniform(k)];
             ChunkWalker<KIND, SUM, MUL, UNIT_W, REL_LDS> walker{p, p.F, col, active ? col : p.F - 1, active, lds_rel, lane,
                                                                 0, 0.0f, false};
@@ -335,7 +339,9 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
             }
         };
 
-        for (int k = part + p.split * widx; k < p.n_chunks; k += p.split * nw) {
+        for (int t = 0;; ++t) {   // serpentine deal of the cost-sorted chunk list (see segment_kernel)
+            const int k = part + p.split * (t * nw + ((t & 1) ? (nw - 1 - widx) : widx));
+            if (k >= p.n_chunks) break;
             const int4 d = p.chunks[uniform(k)];
             const uint32_t *meta = p.meta + d.x;
             const float *wts = UNIT_W ? nullptr : p.weight + d.x;
