@@ -133,6 +133,21 @@ int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd_host, const float 
                                     const float *output, const float *output_grad, float *d_weight,
                                     int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream);
 
+
+/*
+ * Dense epilogue of one Bellman-Ford layer, fused (dim must be 64, the shipped architecture):
+ *     out = [input +]  relu?( LayerNorm?( Linear( cat[input, update] ) ) )
+ * replaces GeneralizedRelationalConv*.combine (/root/reference/ultra/layer.py:184-190, :386-392: cat, nn.Linear,
+ * nn.LayerNorm, relu) and, when `shortcut` is set, the caller's `hidden + layer_input`
+ * (ultra/model.py:126-127, ultra/rel_model.py:371-372).
+ *   input, update, out : [rows, 64] fp32 (a row = one (node, query) pair);  weight [64, 128] = nn.Linear.weight;
+ *   bias [64];  ln_weight / ln_bias [64] or both NULL (no LayerNorm);  relu, shortcut: 0 / 1.
+ * Forward only (inference); training keeps the ATen ops so that autograd sees them.
+ */
+int ultra_combine_forward_f32(const float *input, const float *update, const float *weight, const float *bias,
+                              const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                              float *out, int64_t rows, int64_t dim, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

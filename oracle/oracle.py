@@ -41,7 +41,7 @@ def lib():
         build()
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_abi_version.restype = ctypes.c_int
-        for name in ("oracle_rspmm_forward", "oracle_rspmm_backward", "oracle_filtered_rank"):
+        for name in ("oracle_rspmm_forward", "oracle_rspmm_backward", "oracle_filtered_rank", "oracle_combine_forward"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -190,3 +190,21 @@ def filtered_rank(pred, mask, target):
     if rc:
         raise RuntimeError("oracle_filtered_rank failed")
     return rank
+
+
+def combine_forward(input, update, weight, bias, gamma=None, beta=None, eps=1e-5, relu=True, shortcut=False):
+    """``ultra/layer.py:386-392`` + the shortcut of ``ultra/model.py:126-127`` in the kernel's summation order."""
+    input = np.ascontiguousarray(input, dtype=np.float32).reshape(-1, 64)
+    update = np.ascontiguousarray(update, dtype=np.float32).reshape(-1, 64)
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    bias = np.ascontiguousarray(bias, dtype=np.float32)
+    assert weight.shape == (64, 128) and bias.shape == (64,) and input.shape == update.shape
+    gamma = None if gamma is None else np.ascontiguousarray(gamma, dtype=np.float32)
+    beta = None if beta is None else np.ascontiguousarray(beta, dtype=np.float32)
+    out = np.empty_like(input)
+    rc = lib().oracle_combine_forward(_p(input), _p(update), _p(weight), _p(bias), _p(gamma), _p(beta),
+                                      ctypes.c_float(eps), int(bool(relu)), int(bool(shortcut)), _p(out),
+                                      _i64(input.shape[0]))
+    if rc:
+        raise RuntimeError("oracle_combine_forward failed")
+    return out

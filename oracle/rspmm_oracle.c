@@ -263,3 +263,52 @@ int oracle_filtered_rank(const float *pred, const uint8_t *mask, const int64_t *
     }
     return 0;
 }
+
+/*
+ * Dense epilogue of one layer: out = [input +] relu( LayerNorm( Linear_{128->64}( cat[input, update] ) ) )
+ * follows ultra/layer.py:386-392 (twin :184-190) -- output = self.linear(torch.cat([input, update], dim=-1));
+ * layer_norm; activation -- and the caller's shortcut, ultra/model.py:126-127.  In the reference these are ATen
+ * calls whose internal summation order is unspecified; the order written here is the HIP kernel's documented one:
+ *   linear:  acc = bias[o]; for s in 0..63: acc = fmaf(in[s], W[o][s], acc); acc = fmaf(up[s], W[o][64+s], acc)
+ *   LayerNorm over 64 values: sums over columns 0..31 and 32..63 taken sequentially and added (lo + hi);
+ *            mean = sum/64, var = sum((x-mean)^2)/64 the same way, y = ((x-mean) * (1/sqrt(var+eps))) * g + b
+ * gamma == NULL: no LayerNorm.  dim is fixed at 64 like the kernel.
+ */
+int oracle_combine_forward(const float *input, const float *update, const float *weight, const float *bias,
+                           const float *gamma, const float *beta, float eps, int relu, int shortcut, float *out,
+                           int64_t rows) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        const float *in = input + r * 64, *up = update + r * 64;
+        float v[64];
+        for (int o = 0; o < 64; ++o) {
+            float acc = bias[o];
+            const float *w = weight + (int64_t)o * 128;
+            for (int s = 0; s < 64; ++s) {
+                acc = fmaf(in[s], w[s], acc);
+                acc = fmaf(up[s], w[64 + s], acc);
+            }
+            v[o] = acc;
+        }
+        if (gamma) {
+            float s0 = 0.0f, s1 = 0.0f;
+            for (int c = 0; c < 32; ++c) { s0 = s0 + v[c]; s1 = s1 + v[32 + c]; }
+            const float mean = (s0 + s1) * (1.0f / 64.0f);
+            float q0 = 0.0f, q1 = 0.0f;
+            for (int c = 0; c < 32; ++c) {
+                float d0 = v[c] - mean, d1 = v[32 + c] - mean;
+                q0 = q0 + d0 * d0;
+                q1 = q1 + d1 * d1;
+            }
+            const float var = (q0 + q1) * (1.0f / 64.0f);
+            const float inv = 1.0f / sqrtf(var + eps);
+            for (int c = 0; c < 64; ++c) v[c] = ((v[c] - mean) * inv) * gamma[c] + beta[c];
+        }
+        if (relu)
+            for (int c = 0; c < 64; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+        if (shortcut)
+            for (int c = 0; c < 64; ++c) v[c] = v[c] + in[c];
+        for (int c = 0; c < 64; ++c) out[r * 64 + c] = v[c];
+    }
+    return 0;
+}

@@ -281,3 +281,36 @@ def test_general_kernel_equals_packed_kernel(oracle, case):
             lib.ultra_rspmm_force_general_path(0)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 4096 + 17, 14541 * 16])
+@pytest.mark.parametrize("ln,relu,shortcut", [(True, True, True), (False, True, False), (True, False, True)])
+def test_fused_combine_matches_oracle_and_torch(oracle, rows, ln, relu, shortcut):
+    """ultra_combine_forward_f32 vs (a) the oracle in the kernel's documented order and (b) the reference's own
+    formulation in torch: relu(LayerNorm(Linear(cat[input, update]))) + input (layer.py:386-392, model.py:126-127)."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = _dev()
+    gen = torch.Generator(device="cpu").manual_seed(rows)
+    x = torch.randn(rows, 64, generator=gen)
+    u = torch.randn(rows, 64, generator=gen) * 3
+    lin = torch.nn.Linear(128, 64)
+    norm = torch.nn.LayerNorm(64)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(64, generator=gen) + 0.5)
+        norm.bias.copy_(torch.randn(64, generator=gen) * 0.1)
+        got = UF.combine_forward(x.to(dev), u.to(dev), lin.weight.to(dev), lin.bias.to(dev),
+                                 norm.weight.to(dev) if ln else None, norm.bias.to(dev) if ln else None, norm.eps,
+                                 relu, shortcut).cpu()
+        ref = lin(torch.cat([x, u], dim=-1))
+        if ln:
+            ref = norm(ref)
+        if relu:
+            ref = torch.relu(ref)
+        if shortcut:
+            ref = ref + x
+    torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
+    sub = slice(0, min(rows, 5000))
+    want = oracle.combine_forward(x[sub].numpy(), u[sub].numpy(), lin.weight.detach().numpy(), lin.bias.detach().numpy(),
+                                  norm.weight.detach().numpy() if ln else None, norm.bias.detach().numpy() if ln else None,
+                                  norm.eps, relu, shortcut)
+    assert np.array_equal(got[sub].numpy(), want), "fused combine differs from the oracle's documented order"

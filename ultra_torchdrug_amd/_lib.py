@@ -47,6 +47,7 @@ EXPORTS = (
     "ultra_rspmm_forward_f32",
     "ultra_rspmm_backward_f32",
     "ultra_rspmm_backward_weight_f32",
+    "ultra_combine_forward_f32",
 )
 
 _lib = None
@@ -95,6 +96,8 @@ def load():
     lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_weight_f32.restype = i32
     lib.ultra_rspmm_backward_weight_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
+    lib.ultra_combine_forward_f32.restype = i32
+    lib.ultra_combine_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, i64, vp]
     if lib.ultra_rspmm_abi_version() != ABI_VERSION:
         raise UltraLibraryError("ABI mismatch: library %d, binding %d" % (lib.ultra_rspmm_abi_version(), ABI_VERSION))
     _lib = lib

@@ -491,6 +491,166 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(const int32_t *row, co
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// combine_kernel: the dense epilogue of one Bellman-Ford layer, fused.
+//     out = [ + input ]  relu( LayerNorm( Linear_{128->64}( cat[input, update] ) ) )
+// = GeneralizedRelationalConv*.combine (/root/reference/ultra/layer.py:184-190, :386-392) followed by the
+// shortcut add of the caller (ultra/model.py:126-127, ultra/rel_model.py:371-372).  In the reference this is
+// cat + Linear + LayerNorm + ReLU + add = 5 launches that move ~5x the bytes of this kernel.
+//
+// One wave = one tile of 32 consecutive rows (a row = one (node, query) pair, 64 floats, contiguous in memory).
+// GEMM on the exact-f32 matrix cores: v_mfma_f32_32x32x2_f32, D[32 rows x 32 outs] per accumulator, two
+// accumulators for the 64 outputs, 64 k-steps.  MFMA numerics are a k-ordered fmaf chain; the k order used here
+// is  in[0], up[0], in[1], up[1], ...  (lane half h = 0 feeds `input`, h = 1 feeds `update`), starting from the
+// bias -- oracle_combine_forward() restates exactly this chain.
+// The 64x128 weight lives in registers for the life of the (persistent) wave: 128 VGPRs per lane.
+// Activations are staged through a wave-private LDS tile (coalesced 1-KiB loads in, row-per-lane reads out,
+// rows padded by one access width => conflict-free ds_read_b128).
+constexpr int kCbRows = 32;
+constexpr int kCbStride = 132;                 // 128 floats + 4 pad
+constexpr int kCbWaves = 4;                    // waves per workgroup
+constexpr int kCbTileFloats = kCbRows * kCbStride;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct CombineParams {
+    const float *input;    // [rows, 64]
+    const float *update;   // [rows, 64]
+    const float *weight;   // [64, 128] row-major (nn.Linear.weight)
+    const float *bias;     // [64]
+    const float *gamma;    // [64] or NULL (no LayerNorm)
+    const float *beta;     // [64]
+    float *out;            // [rows, 64]
+    long long rows;
+    float eps;
+    int relu;
+    int shortcut;
+};
+
+__global__ __launch_bounds__(kCbWaves * 64, 2) void combine_kernel(const CombineParams p) {
+    extern __shared__ __attribute__((aligned(16))) float cb_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wl = uniform(threadIdx.x >> 6);
+    float *tile = cb_lds + wl * kCbTileFloats;
+    const int i = lane & 31, h = lane >> 5;
+    const long long n_tiles = (p.rows + kCbRows - 1) / kCbRows;
+    const long long wave_global = (long long)blockIdx.x * kCbWaves + wl;
+    const long long wave_total = (long long)gridDim.x * kCbWaves;
+
+    // B operand fragments: lane (j = l & 31, h): W[j + 32 t][64 h + s], s = 0..63, t = 0, 1
+    float w0[64], w1[64];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p.weight + (long long)i * 128 + 64 * h + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(p.weight + (long long)(i + 32) * 128 + 64 * h + 4 * q);
+        w0[4 * q + 0] = a.x; w0[4 * q + 1] = a.y; w0[4 * q + 2] = a.z; w0[4 * q + 3] = a.w;
+        w1[4 * q + 0] = b.x; w1[4 * q + 1] = b.y; w1[4 * q + 2] = b.z; w1[4 * q + 3] = b.w;
+    }
+    const float bias0 = p.bias[i], bias1 = p.bias[i + 32];
+    // LayerNorm role of this lane: row = lane >> 1, columns [32 * (lane & 1), +32)
+    const int ln_row = lane >> 1, ln_half = lane & 1;
+
+    for (long long t = wave_global; t < n_tiles; t += wave_total) {
+        const long long row0 = t * kCbRows;
+        const long long last = p.rows - 1;
+        // ---- stage the tile: 8 + 8 coalesced 1-KiB loads (4 rows each), rows past the end re-read the last row
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
+            long long gr = row0 + r;
+            gr = gr < last ? gr : last;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(p.input + gr * 64 + c);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(p.update + gr * 64 + c);
+            *reinterpret_cast<f32x4 *>(tile + r * kCbStride + c) = a;
+            *reinterpret_cast<f32x4 *>(tile + r * kCbStride + 64 + c) = b;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+        // ---- GEMM: acc_t[r] = D[row = (r&3) + 8(r>>2) + 4h][out = i + 32 t]
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = bias0; acc1[r] = bias1; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(tile + i * kCbStride + 64 * h + 4 * q);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w0[4 * q + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w1[4 * q + 0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w0[4 * q + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w1[4 * q + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w0[4 * q + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w1[4 * q + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w0[4 * q + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w1[4 * q + 3], acc1, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all A-fragment reads done before `update` is overwritten
+
+        // ---- D -> LDS over the (consumed) `update` half of the tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[row * kCbStride + 64 + i] = acc0[r];
+            tile[row * kCbStride + 96 + i] = acc1[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // ---- LayerNorm + ReLU + shortcut: two lanes per row, 32 columns each, sums in column order
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(tile + ln_row * kCbStride + 64 + 32 * ln_half + 4 * q);
+            v[4 * q + 0] = d.x; v[4 * q + 1] = d.y; v[4 * q + 2] = d.z; v[4 * q + 3] = d.w;
+        }
+        if (p.gamma != nullptr) {
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) s = s + v[c];
+            const float so = __shfl_xor(s, 1, 64);
+            const float mean = (ln_half == 0 ? s + so : so + s) * (1.0f / 64.0f);
+            float ss = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) { const float dlt = v[c] - mean; ss = ss + dlt * dlt; }
+            const float sso = __shfl_xor(ss, 1, 64);
+            const float var = (ln_half == 0 ? ss + sso : sso + ss) * (1.0f / 64.0f);
+            const float inv = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const int col = 32 * ln_half + c;
+                v[c] = ((v[c] - mean) * inv) * p.gamma[col] + p.beta[col];
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+        }
+        if (p.shortcut) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(tile + ln_row * kCbStride + 32 * ln_half + 4 * q);
+                v[4 * q + 0] = v[4 * q + 0] + x.x; v[4 * q + 1] = v[4 * q + 1] + x.y;
+                v[4 * q + 2] = v[4 * q + 2] + x.z; v[4 * q + 3] = v[4 * q + 3] + x.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            f32x4 d;
+            d.x = v[4 * q + 0]; d.y = v[4 * q + 1]; d.z = v[4 * q + 2]; d.w = v[4 * q + 3];
+            *reinterpret_cast<f32x4 *>(tile + ln_row * kCbStride + 64 + 32 * ln_half + 4 * q) = d;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // ---- coalesced store of the finished 32 x 64 tile (8 KiB contiguous in `out`)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(tile + r * kCbStride + 64 + c);
+            if (row0 + r < p.rows) *reinterpret_cast<f32x4 *>(p.out + (row0 + r) * 64 + c) = d;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile is rewritten by the next iteration
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 
 thread_local int g_last_hip_error = 0;
@@ -876,6 +1036,40 @@ int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd, const float *rela
     ULTRA_WCASE(ULTRA_SUM_MAX, ULTRA_MUL_MUL)
     ULTRA_WCASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
 #undef ULTRA_WCASE
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
+
+int ultra_combine_forward_f32(const float *input, const float *update, const float *weight, const float *bias,
+                              const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                              float *out, int64_t rows, int64_t dim, void *stream) {
+    if (dim != 64) return ULTRA_ERR_BAD_SHAPE;     // the shipped architecture: 64 -> 64 with a 128-wide concat
+    if (rows < 0) return ULTRA_ERR_BAD_SHAPE;
+    if (rows == 0) return ULTRA_OK;
+    if (input == nullptr || update == nullptr || weight == nullptr || bias == nullptr || out == nullptr)
+        return ULTRA_ERR_NULL_POINTER;
+    if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo *di = nullptr;
+    int rc = device_info(dev, &di);
+    if (rc) return rc;
+    CombineParams p;
+    p.input = input; p.update = update; p.weight = weight; p.bias = bias; p.gamma = ln_weight; p.beta = ln_bias;
+    p.out = out; p.rows = rows; p.eps = ln_eps; p.relu = relu; p.shortcut = shortcut;
+    const long long n_tiles = (rows + kCbRows - 1) / kCbRows;
+    long long blocks = (n_tiles + kCbWaves - 1) / kCbWaves;
+    const long long resident = (long long)di->n_cu * 2;
+    if (blocks > resident) blocks = resident;
+    const size_t lds = (size_t)kCbWaves * kCbTileFloats * sizeof(float);
+    static bool attr_set[16] = {false};
+    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)blocks), dim3(kCbWaves * 64), lds, static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
 }

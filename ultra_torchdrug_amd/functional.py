@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -146,6 +146,28 @@ def rspmm_backward_weight(csr, relation, input, output, output_grad, sum="add", 
             csr.fwd.pointer, relation.data_ptr(), input.data_ptr(), output.data_ptr() if output is not None else None,
             output_grad.data_ptr(), d_w.data_ptr(), csr.shape[2], input.shape[1], sum_op, mul_op, _stream()))
     return d_w
+
+
+def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False):
+    """Fused ``combine`` (+ shortcut) of one layer, forward only: ``[input +] relu(LN(Linear(cat[input, update])))``
+    (``ultra/layer.py:386-392``, ``ultra/model.py:126-127``).  ``input`` / ``update``: ``(..., 64)`` fp32 on the GPU."""
+    if input.shape != update.shape or input.shape[-1] != 64 or tuple(weight.shape) != (64, 128):
+        raise RuntimeError("combine_forward handles 64 -> 64 layers with a (64, 128) weight; got input %s, update %s, "
+                           "weight %s" % (tuple(input.shape), tuple(update.shape), tuple(weight.shape)))
+    tensors = [input, update, weight, bias] + ([ln_weight, ln_bias] if ln_weight is not None else [])
+    if any(t.dtype != torch.float32 or not t.is_cuda or t.device != input.device for t in tensors):
+        raise RuntimeError("combine_forward needs fp32 tensors on one HIP device (no CPU fallback)")
+    input, update = input.contiguous(), update.contiguous()
+    out = torch.empty_like(input)
+    rows = input.numel() // 64
+    lib = _lib.load()
+    with torch.cuda.device(input.device):
+        _lib.check(lib.ultra_combine_forward_f32(
+            input.data_ptr(), update.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+            ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
+            ln_bias.contiguous().data_ptr() if ln_weight is not None else None,
+            float(ln_eps), int(bool(relu)), int(bool(shortcut)), out.data_ptr(), rows, 64, _stream()))
+    return out
 
 
 class _RSPMMFunction(torch.autograd.Function):

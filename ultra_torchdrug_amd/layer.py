@@ -64,9 +64,32 @@ class _RelationalConvBase(nn.Module):
     def _relation_table(self, graph, batch_size):
         raise NotImplementedError
 
-    def forward(self, graph, input):
+    def forward(self, graph, input, shortcut=False):
+        """``MessagePassingBase.forward``: ``combine(input, message_and_aggregate(graph, input))``.  ``shortcut``
+        additionally adds ``input`` (the caller's ``hidden + layer_input``, ``ultra/model.py:126-127``) so that the
+        inference path can run combine + shortcut as ONE HIP kernel."""
         update = self.message_and_aggregate(graph, input)
-        return self.combine(input, update)
+        if self._fusable(input, update):
+            ln = self.layer_norm
+            return functional.combine_forward(input, update, self.linear.weight, self.linear.bias,
+                                              ln.weight if ln else None, ln.bias if ln else None,
+                                              ln.eps if ln else 1e-5, relu=self.activation is F.relu, shortcut=shortcut)
+        output = self.combine(input, update)
+        return output + input if shortcut else output
+
+    def _no_grad(self, *tensors):
+        return not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors if t is not None)
+
+    def _fusable(self, input, update):
+        """The fused epilogue kernel covers the shipped layer shape: 64 -> 64, concat of 2, relu or no activation,
+        inference (autograd keeps the ATen ops)."""
+        ln = self.layer_norm
+        return (input.is_cuda and input.dtype == torch.float32 and input.shape == update.shape
+                and input.shape[-1] == 64 and self.output_dim == 64 and tuple(self.linear.weight.shape) == (64, 128)
+                and (self.activation is F.relu or not self.activation)
+                and (ln is None or (ln.elementwise_affine and ln.bias is not None))
+                and hasattr(functional, "combine_forward")
+                and self._no_grad(input, update, self.linear.weight, self.linear.bias))
 
     # ---- O(E) definition, used for rotate / graphs that require grad (layer.py:52-109, :232-296) ---------
     def message(self, graph, input):
@@ -144,16 +167,25 @@ class _RelationalConvBase(nn.Module):
         degree_out = None
         if kind in ("mean", "pna"):
             degree_out = graph.degree_out.unsqueeze(-1) + 1
+        # inference: `update + boundary` / `max(update, boundary)` ride along in the rspmm kernel (bit-identical)
+        fuse_bound = (bound and input.is_cuda and hasattr(functional, "rspmm_forward")
+                      and self._no_grad(input, relation_input, boundary))
         if kind in ("sum", "mean"):
-            update = rspmm(adjacency, relation_input, input, sum="add", mul=mul)
-            if bound:
-                update = update + boundary
+            if fuse_bound:
+                update = functional.rspmm_forward(adjacency, relation_input, input, "add", mul, add_rows=boundary)
+            else:
+                update = rspmm(adjacency, relation_input, input, sum="add", mul=mul)
+                if bound:
+                    update = update + boundary
             if kind == "mean":
                 update = update / degree_out
         elif kind == "max":
-            update = rspmm(adjacency, relation_input, input, sum="max", mul=mul)
-            if bound:
-                update = torch.max(update, boundary)
+            if fuse_bound:
+                update = functional.rspmm_forward(adjacency, relation_input, input, "max", mul, add_rows=boundary)
+            else:
+                update = rspmm(adjacency, relation_input, input, sum="max", mul=mul)
+                if bound:
+                    update = torch.max(update, boundary)
         else:
             sum = rspmm(adjacency, relation_input, input, sum="add", mul=mul)
             sq_sum = rspmm(adjacency, relation_input ** 2, input ** 2, sum="add", mul=mul)

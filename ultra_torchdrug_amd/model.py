@@ -102,9 +102,9 @@ class TransferNBFNet(nn.Module):
                 step_graph = graph.clone()
                 step_graph.query, step_graph.boundary = query, boundary
                 step_graph.requires_grad = True
-            hidden = conv(step_graph, layer_input)
-            if self.short_cut and hidden.shape == layer_input.shape:
-                hidden = hidden + layer_input
+            # the shortcut `hidden + layer_input` (model.py:126-127) is applied inside the layer call
+            hidden = conv(step_graph, layer_input,
+                          shortcut=self.short_cut and conv.output_dim == layer_input.shape[-1])
             hiddens.append(hidden)
             step_graphs.append(step_graph)
             layer_input = hidden

@@ -73,9 +73,8 @@ class CustomNBFNet(nn.Module):
     def _run_layers(self, graph, boundary):
         layer_input = boundary
         for conv in self.layers:
-            hidden = conv(graph, layer_input)
-            if self.short_cut and hidden.shape == layer_input.shape:
-                hidden = hidden + layer_input
+            # shortcut (rel_model.py:371-372) applied inside the layer call
+            hidden = conv(graph, layer_input, shortcut=self.short_cut and conv.output_dim == layer_input.shape[-1])
             layer_input = hidden
         return layer_input
 
