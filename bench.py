@@ -207,11 +207,32 @@ def main():
 
     # ---------------- MRR of the HIP path on seeded queries (after the timed region) ----------------
     mrr = None
+    mrr_check = None
     if args.mrr_queries > 0:
         with torch.no_grad():
             ranks = [task.rank_batch(shard[i:i + B]) for i in range(0, min(args.mrr_queries, len(shard)), B)]
         ranks = torch.cat(ranks)
         mrr = float((1.0 / ranks.float()).mean())
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # the same first batch once more with the CPU oracle in place of the HIP operator (checker, not product)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_ops import oracle_rspmm
+            from ultra_torchdrug_amd.relcsr import PIECE_LEN
+            cpu_task = build_ultra(n_rel)
+            cpu_task.load_state_dict({k: v.cpu() for k, v in task.state_dict().items()})
+            cpu_task.preprocess(Graph(torch.from_numpy(triples), num_node=n_node, num_relation=n_rel),
+                                torch.from_numpy(fact_mask)).eval()
+            with torch.no_grad(), oracle_rspmm(PIECE_LEN):
+                batch_cpu = shard[:B].cpu()
+                pred_cpu = cpu_task.predict(batch_cpu)
+                ranks_cpu = cpu_task.get_ranking(pred_cpu, cpu_task.target(batch_cpu))
+            with torch.no_grad():
+                pred_gpu = task.predict(shard[:B]).cpu()
+            mrr_check = {"queries": int(B), "mrr_hip": float((1.0 / ranks[:B].float()).mean()),
+                         "mrr_cpu_oracle": float((1.0 / ranks_cpu.float()).mean()),
+                         "ranks_identical": int((ranks[:B].cpu() == ranks_cpu).sum()), "ranks_total": int(ranks_cpu.numel()),
+                         "max_abs_score_diff": float((pred_gpu - pred_cpu).abs().max()),
+                         "weights": "seeded random init (td_ultra_3g/4g.pth are missing blobs)"}
 
     if rank == 0:
         result = {
@@ -234,6 +255,7 @@ def main():
                          "note": "algorithmic bytes/launch = %d (SURVEY 8d); input (%.0f MB) is Infinity-Cache/L2 "
                                  "resident at this size, so achieved may exceed HBM peak" % (algo, n_node * F * 4 / 1e6)},
             "mrr_hip": mrr,
+            "mrr_check": mrr_check,
         }
         if world == 1 and not args.no_cpu_baseline:
             und_np = {"dst": und.edge_list[:, 1].cpu().numpy(), "src": und.edge_list[:, 0].cpu().numpy(),
