@@ -90,6 +90,11 @@ int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_ho
  * handles owned by the caller, passed as void*; NULL = off).  One-shot: cleared by the call that uses it.
  */
 int ultra_rspmm_profile_next(void *start_event, void *stop_event);
+/* hipEvent_t helpers for the hook above, so that the events come from the HIP runtime this library runs on
+ * (a process may hold more than one copy of libamdhip64).  elapsed_ms synchronises on stop_event first. */
+int ultra_rspmm_event_create(void **event_host);
+int ultra_rspmm_event_destroy(void *event);
+int ultra_rspmm_event_elapsed_ms(void *start_event, void *stop_event, float *ms_host);
 
 /* Test/bench knob: non-zero forces the general kernel even where the packed fast path applies (process-wide). */
 int ultra_rspmm_force_general_path(int on);

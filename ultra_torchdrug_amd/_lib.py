@@ -42,6 +42,9 @@ EXPORTS = (
     "ultra_rspmm_last_hip_error",
     "ultra_rspmm_device_info",
     "ultra_rspmm_profile_next",
+    "ultra_rspmm_event_create",
+    "ultra_rspmm_event_destroy",
+    "ultra_rspmm_event_elapsed_ms",
     "ultra_rspmm_force_general_path",
     "ultra_rspmm_workspace_bytes",
     "ultra_rspmm_forward_f32",
@@ -86,6 +89,12 @@ def load():
     lib.ultra_rspmm_device_info.argtypes = [i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.c_char_p, sz]
     lib.ultra_rspmm_profile_next.restype = i32
     lib.ultra_rspmm_profile_next.argtypes = [vp, vp]
+    lib.ultra_rspmm_event_create.restype = i32
+    lib.ultra_rspmm_event_create.argtypes = [ctypes.POINTER(vp)]
+    lib.ultra_rspmm_event_destroy.restype = i32
+    lib.ultra_rspmm_event_destroy.argtypes = [vp]
+    lib.ultra_rspmm_event_elapsed_ms.restype = i32
+    lib.ultra_rspmm_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.ultra_rspmm_force_general_path.restype = i32
     lib.ultra_rspmm_force_general_path.argtypes = [i32]
     lib.ultra_rspmm_workspace_bytes.restype = sz

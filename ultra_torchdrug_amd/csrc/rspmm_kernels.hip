@@ -841,7 +841,15 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
     const int grid = blocks_per_label * kXcd;
     hipEvent_t ev_start = g_prof_start, ev_stop = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
-    if (ev_start != nullptr) HIP_TRY(hipEventRecord(ev_start, stream));
+    // (not while the stream is being captured: the ROCm 7.0 runtime bundled with PyTorch rejects external
+    // event-record nodes, so the hook is simply ignored inside a hipGraph capture)
+    if (ev_start != nullptr || ev_stop != nullptr) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        HIP_TRY(hipStreamIsCapturing(stream, &cs));
+        if (cs != hipStreamCaptureStatusNone) ev_start = ev_stop = nullptr;
+    }
+    auto stamp = [&](hipEvent_t ev) -> hipError_t { return hipEventRecord(ev, stream); };
+    if (ev_start != nullptr) HIP_TRY(stamp(ev_start));
     // packed fast path: forward and sum-backward d_input, when the plan carries packed words, the relation
     // tile fits LDS and the gathered matrix is addressable with a 32-bit byte offset
     bool use_packed = false;
@@ -881,7 +889,7 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
         rc = launch_ops<KIND>(p, sum_op, mul_op, seg->weight == nullptr, rel_lds, grid, rel_lds ? lds_need : 0, stream);
         if (rc) return rc;
     }
-    if (ev_stop != nullptr) HIP_TRY(hipEventRecord(ev_stop, stream));
+    if (ev_stop != nullptr) HIP_TRY(stamp(ev_stop));
 
     if (seg->n_long_rows > 0) {
         FixParams fp;
@@ -939,6 +947,26 @@ int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_ho
 
 int ultra_rspmm_force_general_path(int on) {
     g_force_general = on != 0;
+    return ULTRA_OK;
+}
+
+int ultra_rspmm_event_create(void **event) {
+    if (event == nullptr) return ULTRA_ERR_NULL_POINTER;
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreate(&e));
+    *event = e;
+    return ULTRA_OK;
+}
+
+int ultra_rspmm_event_destroy(void *event) {
+    if (event != nullptr) HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return ULTRA_OK;
+}
+
+int ultra_rspmm_event_elapsed_ms(void *start_event, void *stop_event, float *ms_host) {
+    if (start_event == nullptr || stop_event == nullptr || ms_host == nullptr) return ULTRA_ERR_NULL_POINTER;
+    HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop_event)));
+    HIP_TRY(hipEventElapsedTime(ms_host, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event)));
     return ULTRA_OK;
 }
 
