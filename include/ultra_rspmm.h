@@ -119,7 +119,7 @@ int ultra_rspmm_forward_f32(const ultra_segments *fwd_host, const float *relatio
 /*
  * Gradients of the call above w.r.t. input and relation
  * replaces rspmm_{sum}_{mul}_backward_cuda(sparse, relation, input, output, output_grad).
- *   by_src / by_rel : the d_input / d_relation plans of the same graph
+ *   by_src / by_rel : the d_input / d_relation plans of the same graph (n_src / n_dst: rows of input / output)
  *   output          : forward result WITHOUT add_rows fused (only read for min/max)
  *   output_grad     : dL/d(output) [n_dst, F]
  *   d_input [n_src, F], d_relation [n_rel, F]: either may be NULL to skip it.
@@ -127,8 +127,8 @@ int ultra_rspmm_forward_f32(const ultra_segments *fwd_host, const float *relatio
 int ultra_rspmm_backward_f32(const ultra_segments *by_src_host, const ultra_segments *by_rel_host,
                              const float *relation, const float *input, const float *output,
                              const float *output_grad, float *d_input, float *d_relation, void *workspace,
-                             size_t workspace_bytes, int64_t n_dst, int64_t n_rel, int64_t F, int sum_op,
-                             int mul_op, void *stream);
+                             size_t workspace_bytes, int64_t n_src, int64_t n_dst, int64_t n_rel, int64_t F,
+                             int sum_op, int mul_op, void *stream);
 
 /*
  * d_weight[e] = sum_f output_grad[dst_e, f] * [out == y] * (relation[r_e, f] MUL input[src_e, f])

@@ -99,7 +99,10 @@ def test_relcsr_matches_oracle_coalesce_and_covers_everything(oracle, kw):
             w = seg.packed.numpy().astype(np.int64)[:seg.n_edges] & 0xFFFFFFFF
             sh = seg.packed_src_shift
             assert np.array_equal(w >> sh, seg.node_a.numpy())
-            assert np.array_equal((w >> 8) & ((1 << (sh - 8)) - 1), seg.rel.numpy())
+            if seg.node_b is None:
+                assert np.array_equal((w >> 8) & ((1 << (sh - 8)) - 1), seg.rel.numpy())
+            else:
+                assert sh == 8                                        # d_relation plan: the row is the relation
             begin = np.zeros(seg.n_edges, int)
             for a, b, r0, r1 in ch:
                 begin[a:b] = r0

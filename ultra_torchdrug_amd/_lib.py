@@ -102,7 +102,7 @@ def load():
     lib.ultra_rspmm_forward_f32.restype = i32
     lib.ultra_rspmm_forward_f32.argtypes = [seg, vp, vp, vp, vp, vp, sz, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_f32.restype = i32
-    lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i32, i32, vp]
+    lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_weight_f32.restype = i32
     lib.ultra_rspmm_backward_weight_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
     lib.ultra_combine_forward_f32.restype = i32

@@ -265,15 +265,18 @@ __global__ __launch_bounds__(kBlock) void segment_kernel(const KParams p) {
 // s_mul_i32), and a batch of 8 edges whose last edge is still in the current row skips all row tests.
 struct PParams {
     const uint32_t *meta;
+    const uint32_t *meta2;   // d_relation only: destination node of each edge (ultra_segments.node_b)
     const float *weight;
     const int4 *chunks;
     const float *relation;
-    const float *gather;     // forward: input [n_src, F]; d_input: output_grad [n_dst, F]
+    const float *gather;     // forward: input [n_src, F]; d_input: output_grad [n_dst, F]; d_relation: input
+    const float *gather2;    // d_relation: output_grad [n_dst, F]
     const float *add_rows;
     float *out;
     float *partial;
     long long F;
     uint32_t gather_bytes;
+    uint32_t gather2_bytes;
     uint32_t row_bytes;
     uint32_t src_shift;
     uint32_t rel_mask;       // ((1 << bitsR) - 1) << 8
@@ -287,9 +290,12 @@ struct PParams {
 
 template <int KIND, int SUM, int MUL, bool UNIT_W>
 __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
-    static_assert(KIND == KIND_FWD || (KIND == KIND_DX && SUM == ULTRA_SUM_ADD), "packed path: forward or sum-backward");
+    static_assert(KIND == KIND_FWD || SUM == ULTRA_SUM_ADD, "packed path: forward, or the backward of sum-aggregation");
     constexpr int RED = (KIND == KIND_FWD) ? SUM : ULTRA_SUM_ADD;
-    constexpr bool NEEDS_REL = (KIND == KIND_FWD) || (MUL == ULTRA_MUL_MUL);
+    // forward / d_input: second operand = relation row (LDS).  d_relation (rows = relations): second operand =
+    // input[src] (a second gather, only for mul), first = output_grad[dst] addressed by the meta2 word.
+    constexpr bool NEEDS_REL = (KIND == KIND_FWD) || (KIND == KIND_DX && MUL == ULTRA_MUL_MUL);
+    constexpr bool TWO_GATHERS = (KIND == KIND_DREL);
     extern __shared__ __attribute__((aligned(16))) float lds_rel[];
     const int lane = threadIdx.x & 63;
     const int wave = uniform(threadIdx.x >> 6);
@@ -300,6 +306,9 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
     const long long F = p.F;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gather), 0, p.gather_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(TWO_GATHERS ? p.gather2 : p.gather), 0,
+                                          TWO_GATHERS ? p.gather2_bytes : p.gather_bytes, 0x00020000);
 
     for (int s = label; s < p.n_slots; s += kXcd) {
         const int tile = s / p.split;
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
             if (k >= p.n_chunks) break;
             const int4 d = p.chunks[uniform(k)];
             const uint32_t *meta = p.meta + d.x;
+            const uint32_t *meta2 = TWO_GATHERS ? p.meta2 + d.x : nullptr;
             const float *wts = UNIT_W ? nullptr : p.weight + d.x;
             const int n = d.y - d.x;
             const bool is_piece = d.w < 0;
@@ -354,20 +364,31 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
             for (; e0 + kUnroll <= n; e0 += kUnroll) {
                 uint32_t m[kUnroll];
                 float wv[kUnroll], gv[kUnroll], rv[kUnroll];
+                uint32_t m2[kUnroll];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     m[u] = meta[e0 + u];
+                    m2[u] = 0;
+                    if constexpr (TWO_GATHERS) m2[u] = meta2[e0 + u];
                     wv[u] = 1.0f;
                     if constexpr (!UNIT_W) wv[u] = wts[e0 + u];
                 }
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u)
-                    gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                          rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
+                for (int u = 0; u < kUnroll; ++u) {
+                    if constexpr (TWO_GATHERS) {
+                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
+                    } else {
+                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     rv[u] = 0.0f;
                     if constexpr (NEEDS_REL) rv[u] = *reinterpret_cast<const float *>(lds_lane + (m[u] & p.rel_mask));
+                    if constexpr (TWO_GATHERS && MUL == ULTRA_MUL_MUL)
+                        rv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
                 }
                 if ((m[kUnroll - 1] & 0xffu) == cur) {   // whole batch in the current row (always true for pieces)
 #pragma unroll
@@ -390,21 +411,32 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                 const int rem = n - e0;
                 uint32_t m[kUnroll];
                 float wv[kUnroll], gv[kUnroll], rv[kUnroll];
+                uint32_t m2[kUnroll];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     const int e = e0 + min(u, rem - 1);
                     m[u] = meta[e];
+                    m2[u] = 0;
+                    if constexpr (TWO_GATHERS) m2[u] = meta2[e];
                     wv[u] = 1.0f;
                     if constexpr (!UNIT_W) wv[u] = wts[e];
                 }
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u)
-                    gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                          rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
+                for (int u = 0; u < kUnroll; ++u) {
+                    if constexpr (TWO_GATHERS) {
+                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
+                    } else {
+                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     rv[u] = 0.0f;
                     if constexpr (NEEDS_REL) rv[u] = *reinterpret_cast<const float *>(lds_lane + (m[u] & p.rel_mask));
+                    if constexpr (TWO_GATHERS && MUL == ULTRA_MUL_MUL)
+                        rv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
                 }
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
@@ -795,14 +827,17 @@ int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, int gri
     } else if constexpr (KIND == KIND_DX) {
         if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, grid, lds, stream);
         return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, grid, 0, stream);
+    } else {
+        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, grid, 0, stream);
+        return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, grid, 0, stream);
     }
     return ULTRA_ERR_BAD_OP;
 }
 
 // Runs one plan: segment_kernel over the chunk schedule, then fixup_kernel over the split rows.
 template <int KIND>
-int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t n_rel, int64_t F, int sum_op, int mul_op,
-             bool wants_rel_lds, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t gather2_rows, int64_t n_rel, int64_t F,
+             int sum_op, int mul_op, bool wants_rel_lds, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     int rc = check_segments(seg);
     if (rc) return rc;
     if (F <= 0 || n_rel < 0 || n_rel > 0x7fffffffLL) return ULTRA_ERR_BAD_SHAPE;
@@ -853,24 +888,30 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
     // packed fast path: forward and sum-backward d_input, when the plan carries packed words, the relation
     // tile fits LDS and the gathered matrix is addressable with a 32-bit byte offset
     bool use_packed = false;
-    if constexpr (KIND == KIND_FWD || KIND == KIND_DX) {
-        const float *gather = (KIND == KIND_FWD) ? p.input : p.grad;
+    {
+        // forward gathers `input`; d_input gathers `output_grad`; d_relation gathers both (grad by node_b, input by node_a)
+        const float *gather = (KIND == KIND_DX) ? p.grad : p.input;
         const unsigned long long gather_bytes = (unsigned long long)gather_rows * (unsigned long long)F * 4ull;
+        const unsigned long long gather2_bytes = (unsigned long long)gather2_rows * (unsigned long long)F * 4ull;
+        const bool lds_ok = (KIND == KIND_DREL) || (lds_need <= (size_t)kMaxLdsBytes && n_rel > 0);
         use_packed = !g_force_general && seg->packed != nullptr && (KIND == KIND_FWD || sum_op == ULTRA_SUM_ADD) &&
-                     lds_need <= (size_t)kMaxLdsBytes && gather_bytes < 0xffff0000ull && n_rel > 0 &&
-                     (unsigned long long)F * 4ull < 0x7fffffffull;
+                     lds_ok && gather_bytes < 0xffff0000ull && gather2_bytes < 0xffff0000ull &&
+                     (unsigned long long)F * 4ull < 0x7fffffffull && (KIND != KIND_DREL || seg->node_b != nullptr);
         if (use_packed) {
             PParams q{};
             q.meta = seg->packed;
+            q.meta2 = reinterpret_cast<const uint32_t *>(seg->node_b);
             q.weight = seg->weight;
             q.chunks = p.chunks;
             q.relation = p.relation;
             q.gather = gather;
+            q.gather2 = p.grad;
             q.add_rows = p.add_rows;
             q.out = p.out;
             q.partial = p.partial;
             q.F = F;
             q.gather_bytes = (uint32_t)gather_bytes;
+            q.gather2_bytes = (uint32_t)gather2_bytes;
             q.row_bytes = (uint32_t)(F * 4);
             q.src_shift = (uint32_t)seg->packed_src_shift;
             q.rel_mask = ((1u << (seg->packed_src_shift - 8)) - 1u) << 8;
@@ -880,7 +921,7 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
             q.split = split;
             q.n_slots = p.n_slots;
             q.blocks_per_label = blocks_per_label;
-            const bool needs_rel = (KIND == KIND_FWD) || (mul_op == ULTRA_MUL_MUL);
+            const bool needs_rel = (KIND == KIND_FWD) || (KIND == KIND_DX && mul_op == ULTRA_MUL_MUL);
             rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, grid, needs_rel ? lds_need : 0, stream);
             if (rc) return rc;
         }
@@ -992,14 +1033,14 @@ int ultra_rspmm_forward_f32(const ultra_segments *fwd, const float *relation, co
     p.input = input;
     p.add_rows = add_rows;
     p.out = out;
-    return run_plan<KIND_FWD>(fwd, p, n_src, n_rel, F, sum_op, mul_op, true, workspace, workspace_bytes,
+    return run_plan<KIND_FWD>(fwd, p, n_src, 0, n_rel, F, sum_op, mul_op, true, workspace, workspace_bytes,
                               static_cast<hipStream_t>(stream));
 }
 
 int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments *by_rel, const float *relation,
                              const float *input, const float *output, const float *output_grad, float *d_input,
-                             float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_dst, int64_t n_rel,
-                             int64_t F, int sum_op, int mul_op, void *stream) {
+                             float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_dst,
+                             int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream) {
     if (output_grad == nullptr || relation == nullptr || input == nullptr) return ULTRA_ERR_NULL_POINTER;
     if (sum_op != ULTRA_SUM_ADD && output == nullptr) return ULTRA_ERR_NULL_POINTER;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1012,7 +1053,7 @@ int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments 
         p.grad = output_grad;
         p.out = d_input;
         const bool needs_rel = (mul_op == ULTRA_MUL_MUL) || (sum_op != ULTRA_SUM_ADD);
-        int rc = run_plan<KIND_DX>(by_src, p, n_dst, n_rel, F, sum_op, mul_op, needs_rel, workspace, workspace_bytes, s);
+        int rc = run_plan<KIND_DX>(by_src, p, n_dst, 0, n_rel, F, sum_op, mul_op, needs_rel, workspace, workspace_bytes, s);
         if (rc) return rc;
     }
     if (d_relation != nullptr) {
@@ -1024,7 +1065,7 @@ int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments 
         p.output = output;
         p.grad = output_grad;
         p.out = d_relation;
-        int rc = run_plan<KIND_DREL>(by_rel, p, 0, n_rel, F, sum_op, mul_op, false, workspace, workspace_bytes, s);
+        int rc = run_plan<KIND_DREL>(by_rel, p, n_src, n_dst, n_rel, F, sum_op, mul_op, false, workspace, workspace_bytes, s);
         if (rc) return rc;
     }
     return ULTRA_OK;

@@ -129,7 +129,7 @@ def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mu
             relation.data_ptr(), input.data_ptr(), output.data_ptr() if output is not None else None,
             output_grad.data_ptr(), d_input.data_ptr() if d_input is not None else None,
             d_relation.data_ptr() if d_relation is not None else None, ws.data_ptr() if ws is not None else None,
-            n_ws * 4, csr.shape[0], csr.shape[2], F, sum_op, mul_op, _stream()))
+            n_ws * 4, csr.shape[1], csr.shape[0], csr.shape[2], F, sum_op, mul_op, _stream()))
     return d_input, d_relation
 
 

@@ -62,11 +62,11 @@ class Segments:
         self.packed, self.packed_src_shift = None, 0
         n_rel = int(rel.max()) + 1 if n_edges else 1
         n_a = int(node_a.max()) + 1 if n_edges else 1
-        bits_rel = max((n_rel - 1).bit_length(), 1)
+        # d_relation plan (node_b given): the row IS the relation, no relation field; the word holds node_a only
+        bits_rel = 0 if node_b is not None else max((n_rel - 1).bit_length(), 1)
         if n_edges and chunk_rows <= 256 and 8 + bits_rel + max((n_a - 1).bit_length(), 1) <= 32:
             delta = row - row_begin[row]
-            word = delta | (rel << 8) | (node_a << (8 + bits_rel))
-            # stored as int32 with the same bit pattern as the unsigned 32-bit word
+            word = delta | ((rel << 8) if bits_rel else 0) | (node_a << (8 + bits_rel))
             word = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(i32)
             # PACK_SLACK zero words after the last edge: the kernel always loads whole batches of 8 words
             self.packed = torch.cat([word, torch.zeros(PACK_SLACK, dtype=i32, device=dev)]).contiguous()
