@@ -237,3 +237,69 @@ def test_relation_graph_construction():
                 if e1 == e2:
                     want.add((r1, r2, etype))
     assert set(map(tuple, rg.edge_list.tolist())) == want
+
+
+def test_edge_removal_by_zero_weight_equals_rebuilding_the_graph():
+    """ultra/model.py:57-74,146-147: the training forward drops the batch's positive edges.  Here that is done by
+    zero weights on the cached plans; it must equal the reference's way (a new, re-sorted graph) exactly."""
+    from oracle_ops import oracle_rspmm
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    triples, n, r = synthetic_triples("S-tiny")
+    torch.manual_seed(1)
+    task = build_ultra(r, hidden_dims=(64, 64), rel_layers=2, num_negative=8)
+    task.preprocess(Graph(_t(triples), num_node=n, num_relation=r)).train()
+    batch = _t(triples[:6])
+    neg = task._strict_negative(*batch.t())
+    task._strict_negative = lambda *a: neg
+    with oracle_rspmm(0):
+        loss_a, _ = task(batch)
+        task.model._removal_by_zero_weight = lambda: False          # the reference's way: edge_mask -> new graph
+        loss_b, _ = task(batch)
+    assert loss_a.item() == loss_b.item()
+    # and the plans really are shared, not rebuilt
+    und = task.model._undirected(task.fact_graph)
+    masked = und.reweighted(und.edge_weight * (torch.arange(und.num_edge) % 7 != 0))
+    assert masked.relcsr.fwd.chunks.data_ptr() == und.relcsr.fwd.chunks.data_ptr()
+    assert masked.relcsr.fwd.weight is not None and und.relcsr.fwd.weight is None
+    assert masked.relcsr.by_rel.node_b.data_ptr() == und.relcsr.by_rel.node_b.data_ptr()
+
+
+def test_inductive_and_multigraph_contexts():
+    """task.py:525-634 (per-split graphs with different entity sets) and :637-890 / engine.py:23-34 (a graph id
+    travels with the batch; graphs have different numbers of relations).  CPU, oracle plays rspmm."""
+    from oracle_ops import oracle_rspmm
+    from ultra_torchdrug_amd import engine
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    tr, n1, r = synthetic_triples((150, 900, 5), 1)
+    te, n2, _ = synthetic_triples((90, 500, 5), 2)            # other entities, same relation vocabulary
+    g_train, g_test = Graph(_t(tr), num_node=n1, num_relation=r), Graph(_t(te), num_node=n2, num_relation=r)
+    torch.manual_seed(0)
+    task = build_ultra(r, hidden_dims=(64, 64), rel_layers=2, num_negative=8)
+    task.preprocess_inductive(g_train, g_train, g_test).eval()
+    with torch.no_grad(), oracle_rspmm(0):
+        p_train = task.use("train").predict(_t(tr[:4]))
+        p_test = task.use("test").predict(_t(te[:4]))
+        ranks = task.rank_batch(_t(te[:4]))
+    assert p_train.shape == (4, 2, n1) and p_test.shape == (4, 2, n2) and ranks.shape == (4, 2)
+    assert (ranks >= 1).all() and (ranks <= n2).all()
+
+    # multi-graph: two datasets with 5 and 3 relations under one set of weights
+    t3, n3, r3 = synthetic_triples((70, 300, 3), 3)
+    multi = build_ultra(r, hidden_dims=(64, 64), rel_layers=2, num_negative=8)
+    multi.add_context("0", g_train)
+    multi.add_context("1", Graph(_t(t3), num_node=n3, num_relation=r3))
+    gen = torch.Generator().manual_seed(0)
+    seen = set()
+    multi.train()
+    with oracle_rspmm(0):
+        for _ in range(6):
+            batch, gid = engine.sample_edges_from_graph(multi, 4, gen)
+            seen.add(gid)
+            loss, _ = multi((batch, gid))
+            assert torch.isfinite(loss) and multi.split == gid
+            assert int(batch[:, 2].max()) < multi.num_relation
+    assert seen == {"0", "1"}

@@ -111,3 +111,33 @@ def test_graphed_predict_equals_eager():
         torch.cuda.synchronize()
         assert torch.equal(got, want)
     assert task.model.check_indices          # the reference's asserts are back on for eager calls
+
+
+def test_inductive_zero_shot_inference_matches_oracle_path():
+    """configs[0] of BASELINE.json in miniature: weights meet a graph with OTHER entities at test time (inductive
+    split, ultra/task.py:525-634); HIP path vs the same model with the CPU oracle as operator."""
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.relcsr import PIECE_LEN
+    from ultra_torchdrug_amd.task import build_ultra
+    tr, n1, r = synthetic_triples((400, 3000, 9), 11)
+    te, n2, _ = synthetic_triples((700, 5000, 9), 12)
+    torch.manual_seed(1024)
+    task = build_ultra(r)
+    g_tr = Graph(torch.from_numpy(tr), num_node=n1, num_relation=r)
+    g_te = Graph(torch.from_numpy(te), num_node=n2, num_relation=r)
+    task.preprocess_inductive(g_tr, g_tr, g_te).eval().use("test")
+    batch = torch.from_numpy(te[:16])
+    with torch.no_grad(), oracle_rspmm(PIECE_LEN):
+        pred_cpu = task.predict(batch)
+        rank_cpu = task.get_ranking(pred_cpu, task.target(batch))
+    dev = torch.device("cuda:0")
+    task.to(dev)
+    with torch.no_grad():
+        pred_gpu = task.predict(batch.to(dev))
+        rank_gpu = task.get_ranking(pred_gpu, task.target(batch.to(dev)))
+    diff = (pred_gpu.cpu() - pred_cpu).abs().max().item()
+    assert pred_gpu.shape == (16, 2, n2) and diff <= SCORE_ATOL
+    mask, target = task.target(batch.to(dev))
+    safe = _near_tie_free(pred_cpu, target.cpu(), mask.cpu(), 2 * diff + 1e-7)
+    assert torch.equal(rank_gpu.cpu()[safe], rank_cpu[safe]) and safe.float().mean() > 0.8

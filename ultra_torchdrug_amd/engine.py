@@ -119,6 +119,19 @@ def evaluate(task, triples, batch_size=16):
     return task.evaluate(ranking), ranking
 
 
+def sample_edges_from_graph(task, batch_size, generator=None):
+    """Multi-graph pre-training batch (``ultra/engine.py:23-34``): draw a graph with probability proportional to its
+    number of fact edges, then ``batch_size`` distinct fact edges of it.  Returns ``(triples, graph_id)``.  Every rank
+    draws independently (ranks are seeded ``seed + rank``, ``script/run_full.py:102-107``), so ranks may train on
+    different graphs in the same step; the gradient all-reduce is also the straggler barrier."""
+    names = sorted(task.contexts)
+    sizes = torch.tensor([task.contexts[n]["fact_graph"].num_edge for n in names], dtype=torch.float)
+    graph_id = names[int(torch.multinomial(sizes / sizes.sum(), 1, generator=generator))]
+    fact = task.contexts[graph_id]["fact_graph"]
+    pick = torch.randperm(fact.num_edge, generator=generator)[:batch_size]
+    return fact.edge_list[pick.to(fact.device)], graph_id
+
+
 def allreduce_gradients(module, average=True):
     """One flat all-reduce over every parameter that has a gradient on this step.  Which parameters have one is
     a static property of the architecture, so all ranks build the same buffer."""

@@ -109,6 +109,19 @@ class Graph:
         edge_weight = self.edge_weight.repeat_interleave(2)
         return Graph(edge_list, edge_weight, self.num_node, num_relation)
 
+    def reweighted(self, edge_weight):
+        """Same nodes, edges and edge order, other weights; the sorted plans (``relcsr``) of this graph are SHARED,
+        only their weight arrays are new.  Used to drop edges for one training step by zeroing them
+        (``ultra/model.py:57-74`` builds a new graph -- and torchdrug re-sorts it -- every step)."""
+        edge_weight = torch.as_tensor(edge_weight, dtype=torch.float, device=self.device)
+        if edge_weight.shape != self.edge_weight.shape:
+            raise ValueError("edge_weight must have one entry per edge")
+        g = Graph(self.edge_list, edge_weight, self.num_node, self.num_relation)
+        g._match_index = self._match_index
+        if self.edge_list.shape[1] == 3:
+            g._relcsr = self.relcsr.with_edge_weights(edge_weight)
+        return g
+
     def edge_mask(self, index):
         """Keep the edges selected by a bool mask or an index tensor; nodes are kept."""
         return Graph(self.edge_list[index], self.edge_weight[index], self.num_node, self.num_relation)
@@ -139,12 +152,17 @@ class Graph:
                 num_match[sel] = self.num_edge
                 orders[c] = torch.arange(self.num_edge, device=self.device)
                 continue
-            key_e = torch.zeros(self.num_edge, dtype=torch.long, device=self.device)
             key_p = torch.zeros(sel.numel(), dtype=torch.long, device=self.device)
             for i in cols:
-                key_e = key_e * sizes[i] + self.edge_list[:, i]
                 key_p = key_p * sizes[i] + pattern[sel, i]
-            key_sorted, order = torch.sort(key_e, stable=True)
+            if self._match_index is None:
+                self._match_index = {}
+            if c not in self._match_index:      # sorted edge keys per wildcard layout, built once per graph
+                key_e = torch.zeros(self.num_edge, dtype=torch.long, device=self.device)
+                for i in cols:
+                    key_e = key_e * sizes[i] + self.edge_list[:, i]
+                self._match_index[c] = torch.sort(key_e, stable=True)
+            key_sorted, order = self._match_index[c]
             lo = torch.searchsorted(key_sorted, key_p, right=False)
             hi = torch.searchsorted(key_sorted, key_p, right=True)
             num_match[sel] = hi - lo

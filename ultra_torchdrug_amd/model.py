@@ -50,8 +50,9 @@ class TransferNBFNet(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    def remove_easy_edges(self, graph, h_index, t_index, r_index=None):
-        """model.py:57-74: drop the batch's own positive edges (and their reverse when ``remove_one_hop``)."""
+    def easy_edge_mask(self, graph, h_index, t_index, r_index=None):
+        """model.py:57-73: True for the edges that stay -- every edge except the batch's own positives (and their
+        reverse when ``remove_one_hop``)."""
         if self.remove_one_hop:
             h_ext = torch.cat([h_index, t_index], dim=-1)
             t_ext = torch.cat([t_index, h_index], dim=-1)
@@ -62,7 +63,17 @@ class TransferNBFNet(nn.Module):
         edge_index = graph.match(pattern)[0]
         keep = torch.ones(graph.num_edge, dtype=torch.bool, device=graph.device)
         keep[edge_index] = False
-        return graph.edge_mask(keep)
+        return keep
+
+    def remove_easy_edges(self, graph, h_index, t_index, r_index=None):
+        """model.py:57-74: a new graph without the batch's positive edges."""
+        return graph.edge_mask(self.easy_edge_mask(graph, h_index, t_index, r_index))
+
+    def _removal_by_zero_weight(self):
+        """Dropping an edge == giving it weight 0 exactly when messages are summed (0 * m adds +0.0); for min/max a
+        zero message is not "no message", and rotate / PNA's degree scaling read the edge list itself."""
+        return all(conv.aggregate_func in ("sum", "sum_nobound", "mean", "mean_nobound")
+                   and conv.message_func in conv.message2mul for conv in self.layers)
 
     def negative_sample_to_tail(self, h_index, t_index, r_index, num_relations):
         """model.py:76-83: rows that corrupt heads become tail queries of the inverse relation."""
@@ -119,8 +130,14 @@ class TransferNBFNet(nn.Module):
 
     def forward(self, graph, rel_query_list, h_index, t_index, r_index=None, all_loss=None, metric=None):
         """model.py:145-194: scores of shape ``h_index.shape``."""
+        keep = None
         if all_loss is not None:
-            graph = self.remove_easy_edges(graph, h_index, t_index, r_index)
+            # training: the batch's own positive edges must not carry messages (model.py:146-147).  The reference
+            # builds (and torchdrug re-sorts) a new graph every step; here the cached plans of the full graph are
+            # reused and the removed edges get weight 0 for this step -- identical sums, no sort.
+            keep = self.easy_edge_mask(graph, h_index, t_index, r_index)
+            if not (graph.num_relation and self._removal_by_zero_weight()):
+                graph, keep = graph.edge_mask(keep), None
 
         self.query = rel_query_list[0]
         if len(rel_query_list) > 1:
@@ -138,6 +155,8 @@ class TransferNBFNet(nn.Module):
         if graph.num_relation:
             num_relations = graph.num_relation
             graph = self._undirected(graph)
+            if keep is not None:        # undirected() interleaves every edge with its inverse
+                graph = graph.reweighted(graph.edge_weight * keep.repeat_interleave(2))
             h_index, t_index, r_index = self.negative_sample_to_tail(h_index, t_index, r_index, num_relations)
         else:
             graph = self.as_relational_graph(graph)

@@ -98,6 +98,17 @@ class Segments:
     def pointer(self):
         return ctypes.byref(self.struct)
 
+    def reweighted(self, weight):
+        """Shallow copy that shares every index array / schedule of this plan and carries other edge weights
+        (``weight``: fp32 [n_edges] in THIS plan's edge order)."""
+        import copy
+        other = copy.copy(self)
+        other.weight = torch.cat([weight.to(torch.float32),
+                                  torch.ones(PACK_SLACK, dtype=torch.float32, device=weight.device)]).contiguous()
+        other.struct = _lib.UltraSegments()
+        other._refresh_struct()
+        return other
+
     @property
     def device(self):
         return self.row.device
@@ -234,12 +245,17 @@ class RelCSR:
 
     @property
     def fwd(self):
+        if self._fwd is None and getattr(self, "_base", None) is not None:
+            self._fwd = self._base.fwd.reweighted(self.weight)
         if self._fwd is None:
             self._fwd = Segments(self.dst, self.src, None, self.rel_id, self._w(), self.shape[0], **self._opts)
         return self._fwd
 
     @property
     def by_src(self):
+        if self._by_src is None and getattr(self, "_base", None) is not None:
+            base = self._base.by_src
+            self._by_src = base.reweighted(self.weight[self._base._by_src_order])
         if self._by_src is None:
             n_dst, n_src, n_rel = self.shape
             key = (self.src * n_dst + self.dst) * max(n_rel, 1) + self.rel_id
@@ -251,6 +267,9 @@ class RelCSR:
 
     @property
     def by_rel(self):
+        if self._by_rel is None and getattr(self, "_base", None) is not None:
+            base = self._base.by_rel
+            self._by_rel = base.reweighted(self.weight[self._base._by_rel_order])
         if self._by_rel is None:
             n_dst, n_src, n_rel = self.shape
             key = (self.rel_id * n_dst + self.dst) * n_src + self.src
@@ -259,6 +278,20 @@ class RelCSR:
             self._by_rel = Segments(self.rel_id[order], self.src[order], self.dst[order], self.rel_id[order],
                                     self._w(order), n_rel, **self._opts)
         return self._by_rel
+
+    def with_edge_weights(self, edge_weight):
+        """RelCSR over the same edge set with other weights, given per ORIGINAL (un-coalesced) edge; duplicates of
+        one triple add up, as ``coalesce()`` would.  Shares the sorted index arrays and chunk schedules."""
+        other = RelCSR.__new__(RelCSR)
+        other.shape, other._opts = self.shape, self._opts
+        other.dst, other.src, other.rel_id = self.dst, self.src, self.rel_id
+        other.edge_of_input, other.n_edges = self.edge_of_input, self.n_edges
+        w = torch.zeros(self.n_edges, dtype=torch.float32, device=self.device)
+        w.index_add_(0, self.edge_of_input, edge_weight.to(torch.float32))
+        other.weight, other.unit_weight = w, False
+        other._base = self
+        other._fwd = other._by_src = other._by_rel = None
+        return other
 
     def degree_in(self):
         """Weighted in-degree per destination row (``graph.degree_out`` of the transposed adjacency)."""

@@ -1,6 +1,7 @@
 """Knowledge-graph-completion task: the caller loop that defines "results" for the hot path.
 
-Mirrors ``/root/reference/ultra/task.py`` for the transductive/inductive single-graph case:
+Mirrors ``/root/reference/ultra/task.py`` -- transductive (``:197-351``), inductive (``:525-634``: per-split graphs)
+and multi-graph pre-training (``:637-890``: one graph context per dataset, batches carry a graph id):
 
 * ``KnowledgeGraphCompletionBase`` ``:22-195``  -- fact-graph split, filter masks (``:65-100``), strict negatives
   (``:102-118``), BCE + self-adversarial loss (``:160-195``);
@@ -52,32 +53,72 @@ class KnowledgeGraphCompletion(nn.Module):
         self.sample_weight = sample_weight
         self.metric_per_rel = metric_per_rel
         self.full_batch_eval = full_batch_eval
-        self.graph = self.fact_graph = None
-        self.rel_graphs = []
+        self.contexts = {}
+        self.split = None
 
     @property
     def device(self):
         return next(self.parameters()).device
 
-    # ------------------------------------------------------------------ preprocessing (task.py:31-63, 215-226)
-    def preprocess(self, graph, fact_mask=None):
-        """``graph``: all triples (train+valid+test) as a :class:`Graph` with (h, t, r) rows; ``fact_mask`` selects
-        the edges message passing may use (train only).  Builds the relation graph(s) from the fact graph."""
-        self.num_entity = graph.num_node
-        self.num_relation = graph.num_relation
-        self.graph = graph
-        self.fact_graph = graph if fact_mask is None else graph.edge_mask(fact_mask)
-        self.rel_graphs = [rel_model.construct_relation_graph(self.fact_graph) for rel_model in self.rel_models]
+    # ------------------------------------------------------------------ graphs (task.py:31-63, 215-226, 539-581, 655-672)
+    # A context = the graphs one call works on: `graph` (all known triples, used to filter the ranking),
+    # `fact_graph` (edges that carry messages) and the relation graph(s) built from the fact graph.  The transductive
+    # task has one ("default"); the inductive task has "train" / "valid" / "test" (task.py:539-581: separate entity
+    # sets, shared relation vocabulary); multi-graph pre-training has one per dataset (task.py:655-672).  They are
+    # plain attributes, not module buffers, so state_dict() holds exactly the tensors a reference checkpoint holds
+    # after util.clean_save.
+    def add_context(self, name, graph, fact_graph=None, fact_mask=None):
+        if fact_graph is None:
+            fact_graph = graph if fact_mask is None else graph.edge_mask(fact_mask)
+        ctx = {"graph": graph, "fact_graph": fact_graph,
+               "rel_graphs": [rel_model.construct_relation_graph(fact_graph) for rel_model in self.rel_models]}
+        self.contexts[str(name)] = ctx
+        if self.split is None:
+            self.split = str(name)
+        return ctx
+
+    def use(self, name):
+        """Select the context subsequent calls work on (the reference's ``self.split``, task.py:590-592)."""
+        if str(name) not in self.contexts:
+            raise KeyError("unknown graph context `%s` (have %s)" % (name, sorted(self.contexts)))
+        self.split = str(name)
         return self
+
+    def _ctx(self, key):
+        if self.split is None:
+            raise RuntimeError("call preprocess() / add_context() first")
+        return self.contexts[self.split][key]
+
+    graph = property(lambda self: self._ctx("graph"))
+    fact_graph = property(lambda self: self._ctx("fact_graph"))
+    rel_graphs = property(lambda self: self._ctx("rel_graphs"))
+    num_entity = property(lambda self: self._ctx("fact_graph").num_node)
+    num_relation = property(lambda self: self._ctx("fact_graph").num_relation)
+
+    def preprocess(self, graph, fact_mask=None):
+        """Transductive setup (task.py:31-63, 215-226): ``graph`` holds all triples (train+valid+test) with (h, t, r)
+        rows; ``fact_mask`` selects the edges message passing may use (train only)."""
+        self.contexts, self.split = {}, None
+        self.add_context("default", graph, fact_mask=fact_mask)
+        return self
+
+    def preprocess_inductive(self, train_graph, valid_graph, test_graph, graph=None, inductive_graph=None):
+        """Inductive setup (task.py:539-581, target :435-450): messages travel on the split's own graph; rankings are
+        filtered against ``graph`` (train/valid) and ``inductive_graph`` (test)."""
+        self.contexts, self.split = {}, None
+        self.add_context("train", graph if graph is not None else train_graph, fact_graph=train_graph)
+        self.add_context("valid", graph if graph is not None else valid_graph, fact_graph=valid_graph)
+        self.add_context("test", inductive_graph if inductive_graph is not None else test_graph, fact_graph=test_graph)
+        return self.use("train")
 
     def to(self, *args, **kwargs):
         super().to(*args, **kwargs)
         device = self.device
-        if self.graph is not None:
-            same = self.fact_graph is self.graph
-            self.graph = self.graph.to(device)
-            self.fact_graph = self.graph if same else self.fact_graph.to(device)
-            self.rel_graphs = [g.to(device) for g in self.rel_graphs]
+        for ctx in self.contexts.values():
+            same = ctx["fact_graph"] is ctx["graph"]
+            ctx["graph"] = ctx["graph"].to(device)
+            ctx["fact_graph"] = ctx["graph"] if same else ctx["fact_graph"].to(device)
+            ctx["rel_graphs"] = [g.to(device) for g in ctx["rel_graphs"]]
         return self
 
     # ------------------------------------------------------------------ filter masks (task.py:65-100)
@@ -114,7 +155,15 @@ class KnowledgeGraphCompletion(nn.Module):
         return [rel_model(rel_graph, None, pos_r_index, all_loss=all_loss, metric=metric)["node_feature"]
                 for rel_model, rel_graph in zip(self.rel_models, self.rel_graphs)]
 
+    def _select(self, batch):
+        """Multi-graph pre-training batches are ``(triples, graph_id)`` (task.py:722-731): switch to that graph."""
+        if isinstance(batch, (tuple, list)):
+            batch, graph_id = batch
+            self.use(graph_id)
+        return batch
+
     def predict(self, batch, all_loss=None, metric=None):
+        batch = self._select(batch)
         pos_h_index, pos_t_index, pos_r_index = batch.t()
         batch_size = len(batch)
         rel_inputs = self.relation_representations(pos_r_index, all_loss, metric)
@@ -143,6 +192,7 @@ class KnowledgeGraphCompletion(nn.Module):
 
     def target(self, batch):
         """task.py:279-295: filter masks over the FULL graph and the true tail / head of each triple."""
+        batch = self._select(batch)
         pos_h_index, pos_t_index, pos_r_index = batch.t()
         t_mask = self._calculate_t_mask(self.graph, pos_h_index, pos_r_index)
         h_mask = self._calculate_h_mask(self.graph, pos_t_index, pos_r_index)
@@ -184,6 +234,7 @@ class KnowledgeGraphCompletion(nn.Module):
 
     # ------------------------------------------------------------------ training loss (task.py:160-195)
     def forward(self, batch, all_loss=None, metric=None):
+        batch = self._select(batch)
         all_loss = torch.tensor(0, dtype=torch.float32, device=batch.device)
         metric = {}
         pred = self.predict(batch, all_loss, metric)
