@@ -272,15 +272,15 @@ def test_general_kernel_equals_packed_kernel(oracle, case):
     assert csr.fwd.packed is not None
     lib = U.require_library()
     outs = []
-    for general in (0, 1):
+    for general in (0, 1, 2):      # 0: packed (+ x staged in LDS when it fits), 1: general kernel, 2: packed, x from L2
         lib.ultra_rspmm_force_general_path(general)
         try:
             outs.append([UF.rspmm_forward(csr, torch.from_numpy(relation).to(dev), torch.from_numpy(x).to(dev), s, m)
                          for s in SUMS for m in MULS])
         finally:
             lib.ultra_rspmm_force_general_path(0)
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 @pytest.mark.parametrize("rows", [1, 31, 32, 33, 4096 + 17, 14541 * 16])

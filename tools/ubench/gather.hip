@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kBlock) void gather_a(const float* tab, const int* 
     for (int i = 0; i < kPerWave; i += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, my[i + u] * (kRowStride * 4), 0));
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, ((unsigned)my[i + u] >> 17) * (kRowStride * 4), 0));
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void gather_b(const float* tab, const int* 
     float acc = 0;
     for (int i = 0; i < kPerWave; i += 32) {
         uint4v v[8];
-        const int mine = my[i + (lane & 31)];   // one vector load of 32 indices
+        const int mine = (int)((unsigned)my[i + (lane & 31)] >> 17);   // one vector load of 32 indices
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int row = __shfl(mine, u * 4 + q, 64);
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void gather_c(const float* tab, const int* 
     float* slot = stage + wl * 512;
     float acc = 0;
     for (int i = 0; i < kPerWave; i += 32) {
-        const int mine = my[i + (lane & 31)];
+        const int mine = (int)((unsigned)my[i + (lane & 31)] >> 17);
 #pragma unroll
         for (int u = 0; u < 8; u += 2) {
             const int row0 = __shfl(mine, u * 4 + q, 64);
@@ -80,12 +80,71 @@ __global__ __launch_bounds__(kBlock) void gather_c(const float* tab, const int* 
     out[(size_t)wave * 64 + lane] = acc;
 }
 
+
+// A2: variant A + what the rspmm kernel adds per edge: packed word (shift + mul for the offset, and-mask for the
+//     relation row), one ds_read_b32 from a 121-KB LDS table, multiply-add.
+__global__ __launch_bounds__(kBlock) void gather_a2(const float* tab, const int* idx, float* out) {
+    extern __shared__ float rel[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 474 * 64; i += kBlock) rel[i] = 1.0f + (i & 7);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const unsigned* my = (const unsigned*)idx + (size_t)wave * kPerWave;
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, kRows * kRowStride * 4, 0x00020000);
+    const char* rl = (const char*)rel + lane * 4;
+    float acc = 0;
+    for (int i = 0; i < kPerWave; i += 8) {
+        float v[8], rv[8]; unsigned m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = my[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, (m[u] >> 17) * (kRowStride * 4), 0));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rv[u] = *(const float*)(rl + (m[u] & 0x1ff00u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u] * rv[u];
+    }
+    out[(size_t)wave * 64 + lane] = acc;
+}
+
+// A3: A2 cut into chunks of 88 edges: a dependent descriptor load in front of every chunk, a row store behind it.
+__global__ __launch_bounds__(kBlock) void gather_a3(const float* tab, const int* idx, const int4* desc, float* out, float* rows) {
+    extern __shared__ float rel[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 474 * 64; i += kBlock) rel[i] = 1.0f + (i & 7);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, kRows * kRowStride * 4, 0x00020000);
+    const char* rl = (const char*)rel + lane * 4;
+    float tot = 0;
+    const int nchunk = kPerWave / 88;
+    for (int c = 0; c < nchunk; ++c) {
+        const int4 d = desc[(size_t)wave * nchunk + c];
+        const unsigned* my = (const unsigned*)idx + d.x;
+        float acc = 0;
+        for (int i = 0; i < d.y; i += 8) {
+            float v[8], rv[8]; unsigned m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m[u] = my[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, (m[u] >> 17) * (kRowStride * 4), 0));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rv[u] = *(const float*)(rl + (m[u] & 0x1ff00u));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u] * rv[u];
+        }
+        rows[(size_t)d.z * kRowStride + lane] = acc;
+        tot += acc;
+    }
+    out[(size_t)wave * 64 + lane] = tot;
+}
+
 int main() {
     int n_cu = 256;
     const int blocks = n_cu, waves = blocks * 16;
     std::vector<int> h((size_t)waves * kPerWave);
     srand(1);
-    for (auto& v : h) v = rand() % kRows;
+    for (auto& v : h) v = ((rand() % kRows) << 17) | ((rand() % 474) << 8);   // packed: row | relation
     float *tab, *out; int* idx;
     hipMalloc(&tab, (size_t)kRows * kRowStride * 4);
     hipMemset(tab, 0, (size_t)kRows * kRowStride * 4);
@@ -94,15 +153,24 @@ int main() {
     hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const double bytes = (double)waves * kPerWave * 256;
-    for (int which = 0; which < 3; ++which) {
+    const int nchunk = kPerWave / 88;
+    std::vector<int4> hd((size_t)waves * nchunk);
+    for (int w = 0; w < waves; ++w) for (int c = 0; c < nchunk; ++c) hd[(size_t)w * nchunk + c] = make_int4(w * kPerWave + c * 88, 88, rand() % kRows, 0);
+    int4* desc; hipMalloc(&desc, hd.size() * sizeof(int4)); hipMemcpy(desc, hd.data(), hd.size() * sizeof(int4), hipMemcpyHostToDevice);
+    float* rows; hipMalloc(&rows, (size_t)kRows * kRowStride * 4);
+    hipFuncSetAttribute((const void*)gather_a2, hipFuncAttributeMaxDynamicSharedMemorySize, 474 * 256);
+    hipFuncSetAttribute((const void*)gather_a3, hipFuncAttributeMaxDynamicSharedMemorySize, 474 * 256);
+    for (int which = 0; which < 5; ++which) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(a);
             if (which == 0) hipLaunchKernelGGL(gather_a, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
             if (which == 1) hipLaunchKernelGGL(gather_b, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
             if (which == 2) hipLaunchKernelGGL(gather_c, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
+            if (which == 3) hipLaunchKernelGGL(gather_a2, dim3(blocks), dim3(kBlock), 474 * 256, 0, tab, idx, out);
+            if (which == 4) hipLaunchKernelGGL(gather_a3, dim3(blocks), dim3(kBlock), 474 * 256, 0, tab, idx, desc, out, rows);
             hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
-            if (rep == 2) printf("variant %c: %.3f ms  %.2f TB/s  %.1f GB/s/CU (%s)\n", 'A' + which, ms, bytes / ms / 1e9, bytes / ms / 1e6 / n_cu, hipGetErrorString(hipGetLastError()));
+            if (rep == 2) printf("variant %d: %.3f ms  %.2f TB/s  %.1f GB/s/CU (%s)\n", which, ms, bytes / ms / 1e9, bytes / ms / 1e6 / n_cu, hipGetErrorString(hipGetLastError()));
         }
     }
     return 0;

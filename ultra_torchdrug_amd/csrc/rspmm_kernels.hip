@@ -38,6 +38,7 @@ constexpr int kUnroll = ULTRA_UNROLL;   // gathers in flight per wave
 constexpr int kXcd = 8;
 constexpr int kFixUnroll = 16;
 constexpr int kMaxLdsBytes = 156 * 1024;   // leave a little of the 160 KiB
+constexpr int kLdsHeader = 16;             // bytes in front of the tables: the workgroup's chunk ticket counter
 
 enum Kind { KIND_FWD = 0, KIND_DX = 1, KIND_DREL = 2 };
 
@@ -217,13 +218,13 @@ struct ChunkWalker {
 
 template <int KIND, int SUM, int MUL, bool UNIT_W, bool REL_LDS>
 __global__ __launch_bounds__(kBlock) void segment_kernel(const KParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds_rel[];
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    int *ticket = reinterpret_cast<int *>(lds_raw);                 // first kLdsHeader bytes
+    float *lds_rel = lds_raw + kLdsHeader / sizeof(float);
     const int lane = threadIdx.x & 63;
-    const int wave = uniform(threadIdx.x >> 6);
     const int label = blockIdx.x % kXcd;          // blocks sharing an XCD (round-robin dispatch; speed only)
     const int bl = blockIdx.x / kXcd;
-    const int widx = bl * kWaves + wave;
-    const int nw = p.blocks_per_label * kWaves;
+    const int nb = p.blocks_per_label;
 
     for (int s = label; s < p.n_slots; s += kXcd) {
         const int tile = s / p.split;
@@ -237,19 +238,26 @@ __global__ __launch_bounds__(kBlock) void segment_kernel(const KParams p) {
                 const long long c = (long long)tile * kTile + (i & 63);
                 lds_rel[i] = (c < p.F) ? p.relation[(long long)r * p.F + c] : 0.0f;
             }
-            __syncthreads();
         }
-        // chunks are sorted heaviest first; dealing them in serpentine order (0..nw-1, nw-1..0, ...) gives every
-        // wavefront a near-equal share (round-robin would hand wave 0 the heaviest chunk of every round)
-        for (int t = 0;; ++t) {
-            const int k = part + p.split * (t * nw + ((t & 1) ? (nw - 1 - widx) : widx));
+        if (threadIdx.x == 0) *ticket = 0;
+        __syncthreads();
+        // Work distribution.  Chunks are sorted heaviest first.  ACROSS workgroups they are dealt statically in
+        // serpentine order (round t: workgroup bl takes chunk t*nb + bl on even t, t*nb + nb-1-bl on odd t);
+        // WITHIN a workgroup the 16 waves draw rounds t from a ticket counter in LDS, so a wave that finishes early
+        // simply takes the next chunk (heavy ones first: LPT) and all waves reach the slot barrier together.
+        // Which wave computes which chunk never affects the result.
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = uniform(t);
+            const int k = part + p.split * (t * nb + ((t & 1) ? (nb - 1 - bl) : bl));
             if (k >= p.n_chunks) break;
             const int4 d = p.chunks[uniform(k)];
             ChunkWalker<KIND, SUM, MUL, UNIT_W, REL_LDS> walker{p, p.F, col, active ? col : p.F - 1, active, lds_rel, lane,
                                                                 0, 0.0f, false};
             walker.run(d);
         }
-        if constexpr (REL_LDS) __syncthreads();
+        __syncthreads();   // all tickets drawn and tables no longer read before the next slot rewrites them
     }
 }
 
@@ -277,6 +285,7 @@ struct PParams {
     long long F;
     uint32_t gather_bytes;
     uint32_t gather2_bytes;
+    int n_gather_rows;
     uint32_t row_bytes;
     uint32_t src_shift;
     uint32_t rel_mask;       // ((1 << bitsR) - 1) << 8
@@ -288,21 +297,24 @@ struct PParams {
     int blocks_per_label;
 };
 
-template <int KIND, int SUM, int MUL, bool UNIT_W>
+template <int KIND, int SUM, int MUL, bool UNIT_W, bool X_LDS>
 __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
+    // X_LDS: the gathered matrix itself is small enough (rows * 256 B next to the relation tile in 156 KB: the
+    // relation graphs, 2R nodes) to be staged in LDS per tile -- every gather is then a conflict-free ds_read_b32.
+    static_assert(!X_LDS || KIND != KIND_DREL, "x-in-LDS is for the single-gather kinds");
     static_assert(KIND == KIND_FWD || SUM == ULTRA_SUM_ADD, "packed path: forward, or the backward of sum-aggregation");
     constexpr int RED = (KIND == KIND_FWD) ? SUM : ULTRA_SUM_ADD;
     // forward / d_input: second operand = relation row (LDS).  d_relation (rows = relations): second operand =
     // input[src] (a second gather, only for mul), first = output_grad[dst] addressed by the meta2 word.
     constexpr bool NEEDS_REL = (KIND == KIND_FWD) || (KIND == KIND_DX && MUL == ULTRA_MUL_MUL);
     constexpr bool TWO_GATHERS = (KIND == KIND_DREL);
-    extern __shared__ __attribute__((aligned(16))) float lds_rel[];
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    int *ticket = reinterpret_cast<int *>(lds_raw);                 // first kLdsHeader bytes
+    float *lds_rel = lds_raw + kLdsHeader / sizeof(float);
     const int lane = threadIdx.x & 63;
-    const int wave = uniform(threadIdx.x >> 6);
     const int label = blockIdx.x % kXcd;
     const int bl = blockIdx.x / kXcd;
-    const int widx = bl * kWaves + wave;
-    const int nw = p.blocks_per_label * kWaves;
+    const int nb = p.blocks_per_label;
     const long long F = p.F;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gather), 0, p.gather_bytes, 0x00020000);
@@ -316,6 +328,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
         const long long col = (long long)tile * kTile + lane;
         const bool active = col < F;
         const uint32_t voff = (uint32_t)((active ? col : F - 1) * 4);
+        float *lds_x = lds_rel + (NEEDS_REL ? p.n_rel * kTile : 0);
         if constexpr (NEEDS_REL) {
             const int total = p.n_rel * kTile;
             for (int i = threadIdx.x; i < total; i += kBlock) {
@@ -323,9 +336,25 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                 const long long c = (long long)tile * kTile + (i & 63);
                 lds_rel[i] = (c < F) ? p.relation[(long long)r * F + c] : 0.0f;
             }
-            __syncthreads();
         }
+        if constexpr (X_LDS) {
+            const int total = p.n_gather_rows * kTile;
+            for (int i = threadIdx.x; i < total; i += kBlock) {
+                const int r = i >> 6;
+                const long long c = (long long)tile * kTile + (i & 63);
+                lds_x[i] = (c < F) ? p.gather[(long long)r * F + c] : 0.0f;
+            }
+        }
+        if (threadIdx.x == 0) *ticket = 0;
+        __syncthreads();
         const char *lds_lane = reinterpret_cast<const char *>(lds_rel) + lane * 4;
+        const char *lds_x_lane = reinterpret_cast<const char *>(lds_x) + lane * 4;
+        // one gather: a 256-B row segment of `gather`, from LDS (X_LDS) or through a buffer load with a scalar offset
+        auto gather_one = [&](uint32_t word) -> float {
+            if constexpr (X_LDS) return *reinterpret_cast<const float *>(lds_x_lane + ((word >> p.src_shift) << 8));
+            else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rsrc, voff, (word >> p.src_shift) * p.row_bytes, 0));
+        };
 
         auto store_row = [&](int r, float v) {
             if (active) {
@@ -348,8 +377,11 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
             }
         };
 
-        for (int t = 0;; ++t) {   // serpentine deal of the cost-sorted chunk list (see segment_kernel)
-            const int k = part + p.split * (t * nw + ((t & 1) ? (nw - 1 - widx) : widx));
+        for (;;) {   // static serpentine deal across workgroups, LDS ticket counter within one (see segment_kernel)
+            int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = uniform(t);
+            const int k = part + p.split * (t * nb + ((t & 1) ? (nb - 1 - bl) : bl));
             if (k >= p.n_chunks) break;
             const int4 d = p.chunks[uniform(k)];
             const uint32_t *meta = p.meta + d.x;
@@ -378,8 +410,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     if constexpr (TWO_GATHERS) {
                         gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
                     } else {
-                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                              rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
+                        gv[u] = gather_one(m[u]);
                     }
                 }
 #pragma unroll
@@ -426,8 +457,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     if constexpr (TWO_GATHERS) {
                         gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
                     } else {
-                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                              rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
+                        gv[u] = gather_one(m[u]);
                     }
                 }
 #pragma unroll
@@ -459,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                 for (int q = row_base + (int)cur + 1; q < d.w; ++q) store_row(q, identity<RED>());
             }
         }
-        if constexpr (NEEDS_REL) __syncthreads();
+        __syncthreads();   // all tickets drawn, tables no longer read
     }
 }
 
@@ -691,6 +721,7 @@ thread_local hipEvent_t g_prof_start = nullptr;
 thread_local hipEvent_t g_prof_stop = nullptr;
 // test/bench knob (ultra_rspmm_force_general_path): run the general kernel even where the packed one applies
 bool g_force_general = false;
+bool g_no_x_lds = false;
 
 #define HIP_TRY(expr)                                   \
     do {                                                \
@@ -753,8 +784,8 @@ int launch_instance(const KParams &p, int grid, size_t lds, hipStream_t stream) 
 template <int KIND, int SUM, int MUL>
 int launch_wl(const KParams &p, bool unit_w, bool rel_lds, int grid, size_t lds, hipStream_t stream) {
     if constexpr (KIND == KIND_DREL) {   // rows are relations: no per-edge relation operand, no LDS table
-        if (unit_w) return launch_instance<KIND, SUM, MUL, true, false>(p, grid, 0, stream);
-        return launch_instance<KIND, SUM, MUL, false, false>(p, grid, 0, stream);
+        if (unit_w) return launch_instance<KIND, SUM, MUL, true, false>(p, grid, kLdsHeader, stream);
+        return launch_instance<KIND, SUM, MUL, false, false>(p, grid, kLdsHeader, stream);
     } else {
         if (unit_w) {
             if (rel_lds) return launch_instance<KIND, SUM, MUL, true, true>(p, grid, lds, stream);
@@ -807,16 +838,23 @@ int launch_with_lds(Kern kern, const Params &p, int grid, size_t lds, hipStream_
 }
 
 template <int KIND, int SUM, int MUL>
-int launch_packed_w(const PParams &p, bool unit_w, int grid, size_t lds, hipStream_t stream) {
-    if (unit_w) return launch_with_lds(packed_kernel<KIND, SUM, MUL, true>, p, grid, lds, stream);
-    return launch_with_lds(packed_kernel<KIND, SUM, MUL, false>, p, grid, lds, stream);
+int launch_packed_w(const PParams &p, bool unit_w, bool x_lds, int grid, size_t lds, hipStream_t stream) {
+    if constexpr (KIND != KIND_DREL) {
+        if (x_lds) {
+            if (unit_w) return launch_with_lds(packed_kernel<KIND, SUM, MUL, true, true>, p, grid, lds, stream);
+            return launch_with_lds(packed_kernel<KIND, SUM, MUL, false, true>, p, grid, lds, stream);
+        }
+    }
+    if (unit_w) return launch_with_lds(packed_kernel<KIND, SUM, MUL, true, false>, p, grid, lds, stream);
+    return launch_with_lds(packed_kernel<KIND, SUM, MUL, false, false>, p, grid, lds, stream);
 }
 
 template <int KIND>
-int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, int grid, size_t lds, hipStream_t stream) {
+int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_lds, int grid, size_t lds,
+                  hipStream_t stream) {
     if constexpr (KIND == KIND_FWD) {
 #define ULTRA_PCASE(S, M) \
-    if (sum_op == S && mul_op == M) return launch_packed_w<KIND_FWD, S, M>(p, unit_w, grid, lds, stream);
+    if (sum_op == S && mul_op == M) return launch_packed_w<KIND_FWD, S, M>(p, unit_w, x_lds, grid, lds, stream);
         ULTRA_PCASE(ULTRA_SUM_ADD, ULTRA_MUL_MUL)
         ULTRA_PCASE(ULTRA_SUM_ADD, ULTRA_MUL_ADD)
         ULTRA_PCASE(ULTRA_SUM_MIN, ULTRA_MUL_MUL)
@@ -825,11 +863,11 @@ int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, int gri
         ULTRA_PCASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
 #undef ULTRA_PCASE
     } else if constexpr (KIND == KIND_DX) {
-        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, grid, lds, stream);
-        return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, grid, 0, stream);
+        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream);
+        return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, x_lds, grid, lds, stream);
     } else {
-        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, grid, 0, stream);
-        return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, grid, 0, stream);
+        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, false, grid, kLdsHeader, stream);
+        return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, false, grid, kLdsHeader, stream);
     }
     return ULTRA_ERR_BAD_OP;
 }
@@ -922,12 +960,20 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
             q.n_slots = p.n_slots;
             q.blocks_per_label = blocks_per_label;
             const bool needs_rel = (KIND == KIND_FWD) || (KIND == KIND_DX && mul_op == ULTRA_MUL_MUL);
-            rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, grid, needs_rel ? lds_need : 0, stream);
+            // small gathered matrix (relation graphs: 2R nodes): stage its tile in LDS next to the relation tile
+            const size_t lds_rel_bytes = needs_rel ? lds_need : 0;
+            const size_t lds_x_bytes = (size_t)gather_rows * kTile * sizeof(float);
+            const bool x_lds = (KIND != KIND_DREL) && !g_no_x_lds && gather_rows > 0 &&
+                               lds_rel_bytes + lds_x_bytes <= (size_t)kMaxLdsBytes;
+            q.n_gather_rows = (int)gather_rows;
+            rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, x_lds, grid,
+                                     kLdsHeader + lds_rel_bytes + (x_lds ? lds_x_bytes : 0), stream);
             if (rc) return rc;
         }
     }
     if (!use_packed) {
-        rc = launch_ops<KIND>(p, sum_op, mul_op, seg->weight == nullptr, rel_lds, grid, rel_lds ? lds_need : 0, stream);
+        rc = launch_ops<KIND>(p, sum_op, mul_op, seg->weight == nullptr, rel_lds, grid,
+                              kLdsHeader + (rel_lds ? lds_need : 0), stream);
         if (rc) return rc;
     }
     if (ev_stop != nullptr) HIP_TRY(stamp(ev_stop));
@@ -987,7 +1033,8 @@ int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_ho
 }
 
 int ultra_rspmm_force_general_path(int on) {
-    g_force_general = on != 0;
+    g_force_general = (on & 1) != 0;      // bit 0: general kernel instead of the packed one
+    g_no_x_lds = (on & 2) != 0;           // bit 1: packed kernel without staging the gathered matrix in LDS
     return ULTRA_OK;
 }
 
