@@ -72,6 +72,8 @@ typedef struct ultra_segments {
     int64_t piece_len;         /* contributions per piece                                               */
     /* optional packed edge words for the fast path (NULL when the ids do not fit in 32 bits):           */
     /*   bits [0,8) row - chunk row_begin | bits [8, src_shift) relation id | bits [src_shift,32) node_a */
+    /*   packed_src_shift == 32: the word holds row delta | relation << 8 only, node ids are read from   */
+    /*   node_a (which then carries 16 readable words of slack after the last edge)                      */
     const uint32_t *packed;
     int64_t packed_src_shift;
 } ultra_segments;

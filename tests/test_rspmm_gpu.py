@@ -314,3 +314,30 @@ def test_fused_combine_matches_oracle_and_torch(oracle, rows, ln, relu, shortcut
                                   norm.weight.detach().numpy() if ln else None, norm.bias.detach().numpy() if ln else None,
                                   norm.eps, relu, shortcut)
     assert np.array_equal(got[sub].numpy(), want), "fused combine differs from the oracle's documented order"
+
+
+@pytest.mark.parametrize("case", ["skewed_hub", "small_weights", "many_relations_no_lds", "isolated_and_ragged_F"])
+def test_wide_id_variants_match_oracle(oracle, case):
+    """Big-graph kernel variants (node ids outside the packed word; relation tile in LDS or, when it does not fit,
+    read through L2), forced on small graphs with `wide_ids=True`: forward and sum-backward, bit for bit."""
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    from ultra_torchdrug_amd.relcsr import PIECE_LEN
+    kw, n, r, F = CASES[case]
+    g = random_graph(seed=zlib.crc32(case.encode()) % 1000 + 3, n_node=n, n_rel=r, **dict(kw, unique=True))
+    relation, x = _inputs(8, n, r, F)
+    grad = np.random.default_rng(3).standard_normal((n, F)).astype(np.float32)
+    csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    dev = _dev()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    csr = RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), None if g["w"] is None else t(g["w"]), n, n, r, wide_ids=True)
+    assert csr.fwd.packed_src_shift == 32 and csr.by_src.packed_src_shift == 32
+    for s in SUMS:
+        for m in MULS:
+            want = oracle.rspmm_forward(csr_o, relation, x, s, m, piece=PIECE_LEN)
+            got = UF.rspmm_forward(csr, t(relation), t(x), s, m)
+            assert _same(got.cpu().numpy(), want), (s, m)
+    for m in MULS:
+        out = oracle.rspmm_forward(csr_o, relation, x, "add", m, piece=PIECE_LEN)
+        d_rel_o, d_x_o = oracle.rspmm_backward(csr_o, relation, x, out, grad, "add", m, piece=PIECE_LEN)
+        d_x, d_rel = UF.rspmm_backward(csr, t(relation), t(x), None, t(grad), "add", m)
+        assert _same(d_x.cpu().numpy(), d_x_o) and _same(d_rel.cpu().numpy(), d_rel_o), m

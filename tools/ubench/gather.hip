@@ -8,8 +8,19 @@
 #include <cstdlib>
 #include <vector>
 
-constexpr int kRows = 14541;          // table rows (FB15k237 nodes)
-constexpr int kRowStride = 1024;      // floats per row (F); we gather one 64-float tile of it
+// table shape: default FB15k237 (14541 rows, stride 1024 floats); `./gather big` = 10M rows of 64 floats (2.56 GB, DRAM-bound)
+#ifdef BIG
+constexpr int kRows = 10000000;
+constexpr int kRowStride = 64;
+#else
+constexpr int kRows = 14541;
+constexpr int kRowStride = 1024;
+#endif
+#ifdef BIG
+constexpr int kShift = 8;
+#else
+constexpr int kShift = 17;
+#endif
 constexpr int kBlock = 1024;
 constexpr int kPerWave = 4096;        // rows gathered per wave
 
@@ -17,12 +28,12 @@ __global__ __launch_bounds__(kBlock) void gather_a(const float* tab, const int* 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const int* my = idx + (size_t)wave * kPerWave;
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, kRows * kRowStride * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, (unsigned)((size_t)kRows * kRowStride * 4 > 0xffffffffull ? 0xffffffffu : (size_t)kRows * kRowStride * 4), 0x00020000);
     float acc = 0;
     for (int i = 0; i < kPerWave; i += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, ((unsigned)my[i + u] >> 17) * (kRowStride * 4), 0));
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, ((unsigned)my[i + u] /*shift*/ >> kShift) * (kRowStride * 4), 0));
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
@@ -37,11 +48,11 @@ __global__ __launch_bounds__(kBlock) void gather_b(const float* tab, const int* 
     const int q = lane >> 4, j = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const int* my = idx + (size_t)wave * kPerWave;
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, kRows * kRowStride * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, (unsigned)((size_t)kRows * kRowStride * 4 > 0xffffffffull ? 0xffffffffu : (size_t)kRows * kRowStride * 4), 0x00020000);
     float acc = 0;
     for (int i = 0; i < kPerWave; i += 32) {
         uint4v v[8];
-        const int mine = (int)((unsigned)my[i + (lane & 31)] >> 17);   // one vector load of 32 indices
+        const int mine = (int)((unsigned)my[i + (lane & 31)] /*shift*/ >> kShift);   // one vector load of 32 indices
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int row = __shfl(mine, u * 4 + q, 64);
@@ -64,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void gather_c(const float* tab, const int* 
     float* slot = stage + wl * 512;
     float acc = 0;
     for (int i = 0; i < kPerWave; i += 32) {
-        const int mine = (int)((unsigned)my[i + (lane & 31)] >> 17);
+        const int mine = (int)((unsigned)my[i + (lane & 31)] /*shift*/ >> kShift);
 #pragma unroll
         for (int u = 0; u < 8; u += 2) {
             const int row0 = __shfl(mine, u * 4 + q, 64);
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void gather_a2(const float* tab, const int*
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const unsigned* my = (const unsigned*)idx + (size_t)wave * kPerWave;
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, kRows * kRowStride * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, (unsigned)((size_t)kRows * kRowStride * 4 > 0xffffffffull ? 0xffffffffu : (size_t)kRows * kRowStride * 4), 0x00020000);
     const char* rl = (const char*)rel + lane * 4;
     float acc = 0;
     for (int i = 0; i < kPerWave; i += 8) {
@@ -98,9 +109,9 @@ __global__ __launch_bounds__(kBlock) void gather_a2(const float* tab, const int*
 #pragma unroll
         for (int u = 0; u < 8; ++u) m[u] = my[i + u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, (m[u] >> 17) * (kRowStride * 4), 0));
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, (m[u] /*shift*/ >> kShift) * (kRowStride * 4), 0));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) rv[u] = *(const float*)(rl + (m[u] & 0x1ff00u));
+        for (int u = 0; u < 8; ++u) rv[u] = *(const float*)(rl + (m[u] & (kShift == 17 ? 0x1ff00u : 0x0u)));
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u] * rv[u];
     }
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void gather_a3(const float* tab, const int*
     for (int i = threadIdx.x; i < 474 * 64; i += kBlock) rel[i] = 1.0f + (i & 7);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, kRows * kRowStride * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, (unsigned)((size_t)kRows * kRowStride * 4 > 0xffffffffull ? 0xffffffffu : (size_t)kRows * kRowStride * 4), 0x00020000);
     const char* rl = (const char*)rel + lane * 4;
     float tot = 0;
     const int nchunk = kPerWave / 88;
@@ -127,9 +138,9 @@ __global__ __launch_bounds__(kBlock) void gather_a3(const float* tab, const int*
 #pragma unroll
             for (int u = 0; u < 8; ++u) m[u] = my[i + u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, (m[u] >> 17) * (kRowStride * 4), 0));
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, (m[u] /*shift*/ >> kShift) * (kRowStride * 4), 0));
 #pragma unroll
-            for (int u = 0; u < 8; ++u) rv[u] = *(const float*)(rl + (m[u] & 0x1ff00u));
+            for (int u = 0; u < 8; ++u) rv[u] = *(const float*)(rl + (m[u] & (kShift == 17 ? 0x1ff00u : 0x0u)));
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += v[u] * rv[u];
         }
@@ -144,7 +155,13 @@ int main() {
     const int blocks = n_cu, waves = blocks * 16;
     std::vector<int> h((size_t)waves * kPerWave);
     srand(1);
-    for (auto& v : h) v = ((rand() % kRows) << 17) | ((rand() % 474) << 8);   // packed: row | relation
+    for (auto& v : h) {
+#ifdef BIG
+        v = (int)((((unsigned)rand() * 32768u + (unsigned)rand()) % kRows) << 8);   // row << 8 (no relation field)
+#else
+        v = ((rand() % kRows) << 17) | ((rand() % 474) << 8);   // packed: row | relation
+#endif
+    }
     float *tab, *out; int* idx;
     hipMalloc(&tab, (size_t)kRows * kRowStride * 4);
     hipMemset(tab, 0, (size_t)kRows * kRowStride * 4);

@@ -285,6 +285,7 @@ struct PParams {
     long long F;
     uint32_t gather_bytes;
     uint32_t gather2_bytes;
+    uint32_t relation_bytes;
     int n_gather_rows;
     uint32_t row_bytes;
     uint32_t src_shift;
@@ -297,11 +298,18 @@ struct PParams {
     int blocks_per_label;
 };
 
-template <int KIND, int SUM, int MUL, bool UNIT_W, bool X_LDS>
+// VAR 0: node id inside the packed word, relation tile in LDS (KG-sized graphs).
+// VAR 1: as 0, and the gathered matrix's tile staged in LDS too (rows * 256 B next to the relation tile in 156 KB:
+//        the relation graphs, 2R nodes) -- every gather is then a conflict-free ds_read_b32.
+// VAR 2: big graphs -- ids do not fit one word: word = row delta | relation << 8, the node id comes from the plan's
+//        node_a array (second scalar load per batch); relation row through a buffer load (table too big for LDS).
+// VAR 3: as 2 with the relation tile in LDS.
+template <int KIND, int SUM, int MUL, bool UNIT_W, int VAR>
 __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
-    // X_LDS: the gathered matrix itself is small enough (rows * 256 B next to the relation tile in 156 KB: the
-    // relation graphs, 2R nodes) to be staged in LDS per tile -- every gather is then a conflict-free ds_read_b32.
-    static_assert(!X_LDS || KIND != KIND_DREL, "x-in-LDS is for the single-gather kinds");
+    constexpr bool X_LDS = (VAR == 1);
+    constexpr bool BIG = (VAR >= 2);
+    constexpr bool REL_GLOBAL = (VAR == 2);
+    static_assert(VAR == 0 || KIND != KIND_DREL, "variants 1-3 are for the single-gather kinds");
     static_assert(KIND == KIND_FWD || SUM == ULTRA_SUM_ADD, "packed path: forward, or the backward of sum-aggregation");
     constexpr int RED = (KIND == KIND_FWD) ? SUM : ULTRA_SUM_ADD;
     // forward / d_input: second operand = relation row (LDS).  d_relation (rows = relations): second operand =
@@ -321,6 +329,8 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
     const __amdgpu_buffer_rsrc_t rsrc2 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(TWO_GATHERS ? p.gather2 : p.gather), 0,
                                           TWO_GATHERS ? p.gather2_bytes : p.gather_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_rel =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.relation), 0, p.relation_bytes, 0x00020000);
 
     for (int s = label; s < p.n_slots; s += kXcd) {
         const int tile = s / p.split;
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
         const bool active = col < F;
         const uint32_t voff = (uint32_t)((active ? col : F - 1) * 4);
         float *lds_x = lds_rel + (NEEDS_REL ? p.n_rel * kTile : 0);
-        if constexpr (NEEDS_REL) {
+        if constexpr (NEEDS_REL && !REL_GLOBAL) {
             const int total = p.n_rel * kTile;
             for (int i = threadIdx.x; i < total; i += kBlock) {
                 const int r = i >> 6;
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
             if (k >= p.n_chunks) break;
             const int4 d = p.chunks[uniform(k)];
             const uint32_t *meta = p.meta + d.x;
-            const uint32_t *meta2 = TWO_GATHERS ? p.meta2 + d.x : nullptr;
+            const uint32_t *meta2 = (TWO_GATHERS || BIG) ? p.meta2 + d.x : nullptr;
             const float *wts = UNIT_W ? nullptr : p.weight + d.x;
             const int n = d.y - d.x;
             const bool is_piece = d.w < 0;
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                 for (int u = 0; u < kUnroll; ++u) {
                     m[u] = meta[e0 + u];
                     m2[u] = 0;
-                    if constexpr (TWO_GATHERS) m2[u] = meta2[e0 + u];
+                    if constexpr (TWO_GATHERS || BIG) m2[u] = meta2[e0 + u];
                     wv[u] = 1.0f;
                     if constexpr (!UNIT_W) wv[u] = wts[e0 + u];
                 }
@@ -409,6 +419,8 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                 for (int u = 0; u < kUnroll; ++u) {
                     if constexpr (TWO_GATHERS) {
                         gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
+                    } else if constexpr (BIG) {
+                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, m2[u] * p.row_bytes, 0));
                     } else {
                         gv[u] = gather_one(m[u]);
                     }
@@ -416,7 +428,9 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     rv[u] = 0.0f;
-                    if constexpr (NEEDS_REL) rv[u] = *reinterpret_cast<const float *>(lds_lane + (m[u] & p.rel_mask));
+                    if constexpr (NEEDS_REL && REL_GLOBAL)
+                        rv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_rel, voff, (m[u] >> 8) * p.row_bytes, 0));
+                    if constexpr (NEEDS_REL && !REL_GLOBAL) rv[u] = *reinterpret_cast<const float *>(lds_lane + (m[u] & p.rel_mask));
                     if constexpr (TWO_GATHERS && MUL == ULTRA_MUL_MUL)
                         rv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                               rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     const int e = e0 + min(u, rem - 1);
                     m[u] = meta[e];
                     m2[u] = 0;
-                    if constexpr (TWO_GATHERS) m2[u] = meta2[e];
+                    if constexpr (TWO_GATHERS || BIG) m2[u] = meta2[e];
                     wv[u] = 1.0f;
                     if constexpr (!UNIT_W) wv[u] = wts[e];
                 }
@@ -456,6 +470,8 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                 for (int u = 0; u < kUnroll; ++u) {
                     if constexpr (TWO_GATHERS) {
                         gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
+                    } else if constexpr (BIG) {
+                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, m2[u] * p.row_bytes, 0));
                     } else {
                         gv[u] = gather_one(m[u]);
                     }
@@ -463,7 +479,9 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     rv[u] = 0.0f;
-                    if constexpr (NEEDS_REL) rv[u] = *reinterpret_cast<const float *>(lds_lane + (m[u] & p.rel_mask));
+                    if constexpr (NEEDS_REL && REL_GLOBAL)
+                        rv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_rel, voff, (m[u] >> 8) * p.row_bytes, 0));
+                    if constexpr (NEEDS_REL && !REL_GLOBAL) rv[u] = *reinterpret_cast<const float *>(lds_lane + (m[u] & p.rel_mask));
                     if constexpr (TWO_GATHERS && MUL == ULTRA_MUL_MUL)
                         rv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                               rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
@@ -838,23 +856,28 @@ int launch_with_lds(Kern kern, const Params &p, int grid, size_t lds, hipStream_
 }
 
 template <int KIND, int SUM, int MUL>
-int launch_packed_w(const PParams &p, bool unit_w, bool x_lds, int grid, size_t lds, hipStream_t stream) {
-    if constexpr (KIND != KIND_DREL) {
-        if (x_lds) {
-            if (unit_w) return launch_with_lds(packed_kernel<KIND, SUM, MUL, true, true>, p, grid, lds, stream);
-            return launch_with_lds(packed_kernel<KIND, SUM, MUL, false, true>, p, grid, lds, stream);
-        }
+int launch_packed_w(const PParams &p, bool unit_w, int var, int grid, size_t lds, hipStream_t stream) {
+#define ULTRA_VAR(V)                                                                                         \
+    if (var == V) {                                                                                          \
+        if (unit_w) return launch_with_lds(packed_kernel<KIND, SUM, MUL, true, V>, p, grid, lds, stream);   \
+        return launch_with_lds(packed_kernel<KIND, SUM, MUL, false, V>, p, grid, lds, stream);              \
     }
-    if (unit_w) return launch_with_lds(packed_kernel<KIND, SUM, MUL, true, false>, p, grid, lds, stream);
-    return launch_with_lds(packed_kernel<KIND, SUM, MUL, false, false>, p, grid, lds, stream);
+    if constexpr (KIND != KIND_DREL) {
+        ULTRA_VAR(1)
+        ULTRA_VAR(2)
+        ULTRA_VAR(3)
+    }
+    ULTRA_VAR(0)
+#undef ULTRA_VAR
+    return ULTRA_ERR_BAD_OP;
 }
 
 template <int KIND>
-int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_lds, int grid, size_t lds,
+int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, int var, int grid, size_t lds,
                   hipStream_t stream) {
     if constexpr (KIND == KIND_FWD) {
 #define ULTRA_PCASE(S, M) \
-    if (sum_op == S && mul_op == M) return launch_packed_w<KIND_FWD, S, M>(p, unit_w, x_lds, grid, lds, stream);
+    if (sum_op == S && mul_op == M) return launch_packed_w<KIND_FWD, S, M>(p, unit_w, var, grid, lds, stream);
         ULTRA_PCASE(ULTRA_SUM_ADD, ULTRA_MUL_MUL)
         ULTRA_PCASE(ULTRA_SUM_ADD, ULTRA_MUL_ADD)
         ULTRA_PCASE(ULTRA_SUM_MIN, ULTRA_MUL_MUL)
@@ -863,11 +886,11 @@ int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_
         ULTRA_PCASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
 #undef ULTRA_PCASE
     } else if constexpr (KIND == KIND_DX) {
-        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream);
-        return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, x_lds, grid, lds, stream);
+        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, var, grid, lds, stream);
+        return launch_packed_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, var, grid, lds, stream);
     } else {
-        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, false, grid, kLdsHeader, stream);
-        return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, false, grid, kLdsHeader, stream);
+        if (mul_op == ULTRA_MUL_MUL) return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, 0, grid, kLdsHeader, stream);
+        return launch_packed_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, 0, grid, kLdsHeader, stream);
     }
     return ULTRA_ERR_BAD_OP;
 }
@@ -931,14 +954,17 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
         const float *gather = (KIND == KIND_DX) ? p.grad : p.input;
         const unsigned long long gather_bytes = (unsigned long long)gather_rows * (unsigned long long)F * 4ull;
         const unsigned long long gather2_bytes = (unsigned long long)gather2_rows * (unsigned long long)F * 4ull;
-        const bool lds_ok = (KIND == KIND_DREL) || (lds_need <= (size_t)kMaxLdsBytes && n_rel > 0);
+        const bool big = seg->packed_src_shift >= 32;          // node ids live in node_a, not in the packed word
+        const bool rel_fits = lds_need <= (size_t)kMaxLdsBytes && n_rel > 0;
+        const unsigned long long relation_bytes = (unsigned long long)n_rel * (unsigned long long)F * 4ull;
+        const bool lds_ok = (KIND == KIND_DREL) || rel_fits || (big && relation_bytes < 0xffff0000ull && n_rel > 0);
         use_packed = !g_force_general && seg->packed != nullptr && (KIND == KIND_FWD || sum_op == ULTRA_SUM_ADD) &&
                      lds_ok && gather_bytes < 0xffff0000ull && gather2_bytes < 0xffff0000ull &&
-                     (unsigned long long)F * 4ull < 0x7fffffffull && (KIND != KIND_DREL || seg->node_b != nullptr);
+                     (unsigned long long)F * 4ull < 0x7fffffffull && (KIND != KIND_DREL || (seg->node_b != nullptr && !big));
         if (use_packed) {
             PParams q{};
             q.meta = seg->packed;
-            q.meta2 = reinterpret_cast<const uint32_t *>(seg->node_b);
+            q.meta2 = reinterpret_cast<const uint32_t *>(big ? seg->node_a : seg->node_b);
             q.weight = seg->weight;
             q.chunks = p.chunks;
             q.relation = p.relation;
@@ -950,9 +976,10 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
             q.F = F;
             q.gather_bytes = (uint32_t)gather_bytes;
             q.gather2_bytes = (uint32_t)gather2_bytes;
+            q.relation_bytes = (uint32_t)(relation_bytes < 0xffff0000ull ? relation_bytes : 0);
             q.row_bytes = (uint32_t)(F * 4);
             q.src_shift = (uint32_t)seg->packed_src_shift;
-            q.rel_mask = ((1u << (seg->packed_src_shift - 8)) - 1u) << 8;
+            q.rel_mask = big ? 0xffffff00u : ((1u << (seg->packed_src_shift - 8)) - 1u) << 8;
             q.n_chunks = p.n_chunks;
             q.n_rel = p.n_rel;
             q.n_tiles = n_tiles;
@@ -961,13 +988,19 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
             q.blocks_per_label = blocks_per_label;
             const bool needs_rel = (KIND == KIND_FWD) || (KIND == KIND_DX && mul_op == ULTRA_MUL_MUL);
             // small gathered matrix (relation graphs: 2R nodes): stage its tile in LDS next to the relation tile
-            const size_t lds_rel_bytes = needs_rel ? lds_need : 0;
             const size_t lds_x_bytes = (size_t)gather_rows * kTile * sizeof(float);
-            const bool x_lds = (KIND != KIND_DREL) && !g_no_x_lds && gather_rows > 0 &&
-                               lds_rel_bytes + lds_x_bytes <= (size_t)kMaxLdsBytes;
+            int var = 0;
+            size_t lds_bytes = needs_rel ? lds_need : 0;
+            if (big) {
+                var = (needs_rel && !rel_fits) ? 2 : 3;
+                if (var == 2) lds_bytes = 0;
+            } else if ((KIND != KIND_DREL) && !g_no_x_lds && gather_rows > 0 &&
+                       lds_bytes + lds_x_bytes <= (size_t)kMaxLdsBytes) {
+                var = 1;
+                lds_bytes += lds_x_bytes;
+            }
             q.n_gather_rows = (int)gather_rows;
-            rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, x_lds, grid,
-                                     kLdsHeader + lds_rel_bytes + (x_lds ? lds_x_bytes : 0), stream);
+            rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var, grid, kLdsHeader + lds_bytes, stream);
             if (rc) return rc;
         }
     }

@@ -38,7 +38,9 @@ class Segments:
     """One reduction plan; owns the device tensors and the ``ultra_segments`` struct pointing at them."""
 
     def __init__(self, row, node_a, node_b, rel, weight, n_rows, chunk_edges=CHUNK_EDGES, chunk_rows=CHUNK_ROWS,
-                 piece_len=PIECE_LEN, balance=True):
+                 piece_len=PIECE_LEN, balance=True, wide_ids=False):
+        """``wide_ids`` forces the big-graph word layout (node ids outside the packed word) even when they would fit
+        -- used by tests to exercise that kernel variant on small graphs."""
         n_edges = int(row.shape[0])
         if n_rows > _INT32_MAX or n_edges > _INT32_MAX:
             raise ValueError("graph too large for int32 indices: %d rows, %d edges" % (n_rows, n_edges))
@@ -64,13 +66,22 @@ class Segments:
         n_a = int(node_a.max()) + 1 if n_edges else 1
         # d_relation plan (node_b given): the row IS the relation, no relation field; the word holds node_a only
         bits_rel = 0 if node_b is not None else max((n_rel - 1).bit_length(), 1)
-        if n_edges and chunk_rows <= 256 and 8 + bits_rel + max((n_a - 1).bit_length(), 1) <= 32:
+        if n_edges and chunk_rows <= 256 and 8 + bits_rel + max((n_a - 1).bit_length(), 1) <= 32 and not (
+                wide_ids and node_b is None):
             delta = row - row_begin[row]
             word = delta | ((rel << 8) if bits_rel else 0) | (node_a << (8 + bits_rel))
             word = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(i32)
             # PACK_SLACK zero words after the last edge: the kernel always loads whole batches of 8 words
             self.packed = torch.cat([word, torch.zeros(PACK_SLACK, dtype=i32, device=dev)]).contiguous()
             self.packed_src_shift = 8 + bits_rel
+        elif n_edges and chunk_rows <= 256 and node_b is None and n_rel <= 2 ** 24:
+            # big graphs: the word keeps row delta | relation << 8; the kernel reads the node id from node_a
+            # (packed_src_shift = 32 says so)
+            word = (row - row_begin[row]) | (rel << 8)
+            word = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(i32)
+            self.packed = torch.cat([word, torch.zeros(PACK_SLACK, dtype=i32, device=dev)]).contiguous()
+            self.packed_src_shift = 32
+            self.node_a = torch.cat([self.node_a, torch.zeros(PACK_SLACK, dtype=i32, device=dev)]).contiguous()
         self.long_rows = long_rows.to(i32).contiguous()
         self.n_pieces = int(n_pieces)
 
@@ -178,7 +189,7 @@ class RelCSR:
     """Coalesced relational adjacency of shape ``(n_dst, n_src, n_rel)`` plus its reduction plans."""
 
     def __init__(self, dst, src, rel, weight, n_dst, n_src, n_rel, chunk_edges=CHUNK_EDGES, chunk_rows=CHUNK_ROWS,
-                 piece_len=PIECE_LEN, balance=True):
+                 piece_len=PIECE_LEN, balance=True, wide_ids=False):
         """``dst/src/rel``: int64 tensors [E] (any order, duplicates allowed); ``weight``: fp32 [E] or None (ones)."""
         dev = dst.device
         dst, src, rel = dst.long(), src.long(), rel.long()
@@ -190,7 +201,8 @@ class RelCSR:
         if float(n_dst) * float(n_src) * float(max(n_rel, 1)) >= 2.0 ** 62:
             raise ValueError("adjacency too large for a 64-bit sort key")
         self.shape = (n_dst, n_src, n_rel)
-        self._opts = dict(chunk_edges=chunk_edges, chunk_rows=chunk_rows, piece_len=piece_len, balance=balance)
+        self._opts = dict(chunk_edges=chunk_edges, chunk_rows=chunk_rows, piece_len=piece_len, balance=balance,
+                          wide_ids=wide_ids)
         if weight is None:
             weight = torch.ones(dst.shape[0], dtype=torch.float32, device=dev)
         weight = weight.to(torch.float32)
