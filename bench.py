@@ -175,7 +175,12 @@ def main():
     if not args.eager:
         with torch.no_grad():
             task.predict(shard[:B])                 # plans, kernel attributes, allocator: before the capture
-        graphed = GraphedPredict(task, shard[:B], warmup=0)
+        try:
+            graphed = GraphedPredict(task, shard[:B], warmup=0)
+        except Exception as err:                    # capture refused (driver / runtime): time the eager path
+            print("bench: hipGraph capture failed (%s); falling back to eager launches" % err, file=sys.stderr)
+            torch.cuda.synchronize()
+            graphed = None
 
     def step(i):
         batch = shard[(i % n_batches) * B:(i % n_batches) * B + B]

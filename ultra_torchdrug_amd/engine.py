@@ -91,7 +91,8 @@ class GraphedPredict:
                     task.predict(self.static_batch)
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph), torch.no_grad():
+            # thread_local: other threads of the process (the RCCL watchdog polls events) must not abort the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
                 self.static_pred = task.predict(self.static_batch)
         finally:
             model.check_indices = True
