@@ -156,6 +156,25 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
                               const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
                               float *out, int64_t rows, int64_t dim, void *stream);
 
+
+/*
+ * Backward of the fused epilogue above (training): replaces what autograd derives for the reference's
+ * cat -> nn.Linear -> nn.LayerNorm -> relu chain (/root/reference/ultra/layer.py:386-392).
+ *   grad_out                 : dL/d(out) [rows, 64]  (the shortcut's own pass-through, d_input += grad_out, is the caller's)
+ *   d_z                      : OUT  dL/dz [rows, 64], z = Linear(cat[input, update]);  d_input = d_z . W[:, :64],
+ *                              d_update = d_z . W[:, 64:]  and  d_bias = sum_rows d_z  are plain GEMM / reductions
+ *   d_ln_weight_partial,
+ *   d_ln_bias_partial        : OUT  [n_ln_waves, 64] per-wave partial sums (sum over dim 0 gives the gradients)
+ *   d_weight_partial         : OUT  [n_wgrad_waves, 64 * 128] per-wave partial slabs of d_weight
+ * ultra_combine_backward_waves() gives the two wave counts for `rows` on `device`.
+ */
+int ultra_combine_backward_waves(int device, int64_t rows, int *n_ln_waves, int *n_wgrad_waves);
+int ultra_combine_backward_f32(const float *input, const float *update, const float *weight, const float *bias,
+                               const float *ln_weight, const float *ln_bias, float ln_eps, int relu,
+                               const float *grad_out, float *d_z, float *d_ln_weight_partial,
+                               float *d_ln_bias_partial, float *d_weight_partial, int64_t rows, int64_t dim,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

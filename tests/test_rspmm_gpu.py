@@ -341,3 +341,48 @@ def test_wide_id_variants_match_oracle(oracle, case):
         d_rel_o, d_x_o = oracle.rspmm_backward(csr_o, relation, x, out, grad, "add", m, piece=PIECE_LEN)
         d_x, d_rel = UF.rspmm_backward(csr, t(relation), t(x), None, t(grad), "add", m)
         assert _same(d_x.cpu().numpy(), d_x_o) and _same(d_rel.cpu().numpy(), d_rel_o), m
+
+
+@pytest.mark.parametrize("rows", [1, 33, 1000, 65536 + 7])
+@pytest.mark.parametrize("ln,relu,shortcut", [(True, True, True), (False, True, False), (True, False, False)])
+def test_fused_combine_backward_matches_autograd_of_the_reference_formulation(rows, ln, relu, shortcut):
+    """functional.combine (fused forward + fused backward) against torch autograd on the reference's own chain
+    cat -> Linear -> LayerNorm -> relu (+ input) (layer.py:386-392, model.py:126-127), evaluated in fp64 on the host.
+    fp32 tolerance: 2e-5 relative to the largest entry of each gradient (reductions over up to 65k rows)."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = _dev()
+    gen = torch.Generator(device="cpu").manual_seed(rows + 17)
+    x = torch.randn(rows, 64, generator=gen)
+    u = torch.randn(rows, 64, generator=gen) * 2
+    gout = torch.randn(rows, 64, generator=gen)
+    lin = torch.nn.Linear(128, 64)
+    norm = torch.nn.LayerNorm(64)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(64, generator=gen) + 0.5)
+        norm.bias.copy_(torch.randn(64, generator=gen) * 0.1)
+
+    # reference chain in fp64
+    lin64, norm64 = torch.nn.Linear(128, 64).double(), torch.nn.LayerNorm(64).double()
+    lin64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    norm64.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    x64, u64 = x.double().requires_grad_(), u.double().requires_grad_()
+    ref = lin64(torch.cat([x64, u64], dim=-1))
+    if ln:
+        ref = norm64(ref)
+    if relu:
+        ref = torch.relu(ref)
+    if shortcut:
+        ref = ref + x64
+    ref.backward(gout.double())
+
+    params = [lin.weight, lin.bias] + ([norm.weight, norm.bias] if ln else [])
+    gpu = [t.detach().to(dev).requires_grad_() for t in [x, u] + params]
+    out = UF.combine(gpu[0], gpu[1], gpu[2], gpu[3], gpu[4] if ln else None, gpu[5] if ln else None, norm.eps, relu, shortcut)
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
+    out.backward(gout.to(dev))
+    want = [x64.grad, u64.grad, lin64.weight.grad, lin64.bias.grad] + ([norm64.weight.grad, norm64.bias.grad] if ln else [])
+    names = ["d_input", "d_update", "d_weight", "d_bias", "d_ln_weight", "d_ln_bias"]
+    for name, g, w in zip(names, gpu, want):
+        scale = w.abs().max().item() + 1e-12
+        err = (g.grad.cpu().double() - w).abs().max().item()
+        assert err <= 2e-5 * scale + 1e-6, "%s: err %.3g vs scale %.3g" % (name, err, scale)

@@ -51,6 +51,8 @@ EXPORTS = (
     "ultra_rspmm_backward_f32",
     "ultra_rspmm_backward_weight_f32",
     "ultra_combine_forward_f32",
+    "ultra_combine_backward_waves",
+    "ultra_combine_backward_f32",
 )
 
 _lib = None
@@ -107,6 +109,10 @@ def load():
     lib.ultra_rspmm_backward_weight_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
     lib.ultra_combine_forward_f32.restype = i32
     lib.ultra_combine_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, i64, vp]
+    lib.ultra_combine_backward_waves.restype = i32
+    lib.ultra_combine_backward_waves.argtypes = [i32, i64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    lib.ultra_combine_backward_f32.restype = i32
+    lib.ultra_combine_backward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, vp, vp, vp, vp, vp, i64, i64, vp]
     if lib.ultra_rspmm_abi_version() != ABI_VERSION:
         raise UltraLibraryError("ABI mismatch: library %d, binding %d" % (lib.ultra_rspmm_abi_version(), ABI_VERSION))
     _lib = lib

@@ -1224,3 +1224,5 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
 }
 
 }  // extern "C"
+
+#include "combine_train.inc"

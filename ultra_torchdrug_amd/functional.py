@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -168,6 +168,69 @@ def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, l
             ln_bias.contiguous().data_ptr() if ln_weight is not None else None,
             float(ln_eps), int(bool(relu)), int(bool(shortcut)), out.data_ptr(), rows, 64, _stream()))
     return out
+
+
+class _CombineFunction(torch.autograd.Function):
+    """Fused epilogue with a fused backward (training).  Forward = ``combine_forward``; only the layer's inputs are
+    saved.  Backward: ``libultra_rspmm`` recomputes z, applies the ReLU mask and LayerNorm-backward and reduces
+    ``d_weight`` on the matrix cores; ``d_input`` / ``d_update`` are two 64x64 GEMMs."""
+
+    @staticmethod
+    def forward(ctx, input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut):
+        out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
+        ctx.save_for_backward(input, update, weight, bias, ln_weight, ln_bias)
+        ctx.flags = (float(ln_eps), bool(relu), bool(shortcut))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        input, update, weight, bias, ln_weight, ln_bias = ctx.saved_tensors
+        ln_eps, relu, shortcut = ctx.flags
+        grad_out = grad_out.contiguous()
+        input_c, update_c = input.contiguous(), update.contiguous()
+        rows = input.numel() // 64
+        lib = _lib.load()
+        dev = input.device
+        import ctypes
+        n_ln, n_wg = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(lib.ultra_combine_backward_waves(dev.index or 0, rows, ctypes.byref(n_ln), ctypes.byref(n_wg)))
+        d_z = torch.empty(rows, 64, dtype=torch.float32, device=dev)
+        has_ln = ln_weight is not None
+        dg_p = torch.empty(n_ln.value, 64, dtype=torch.float32, device=dev) if has_ln else None
+        db_p = torch.empty(n_ln.value, 64, dtype=torch.float32, device=dev) if has_ln else None
+        dw_p = torch.empty(n_wg.value, 64 * 128, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_combine_backward_f32(
+                input_c.data_ptr(), update_c.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                ln_weight.contiguous().data_ptr() if has_ln else None, ln_bias.contiguous().data_ptr() if has_ln else None,
+                ln_eps, int(relu), grad_out.data_ptr(), d_z.data_ptr(), dg_p.data_ptr() if has_ln else None,
+                db_p.data_ptr() if has_ln else None, dw_p.data_ptr(), rows, 64, _stream()))
+        needs = ctx.needs_input_grad
+        d_input = d_update = d_weight = d_bias = d_g = d_b = None
+        if needs[0]:
+            d_input = torch.mm(d_z, weight[:, :64]).view_as(input)
+            if shortcut:
+                d_input = d_input + grad_out.view_as(input)
+        if needs[1]:
+            d_update = torch.mm(d_z, weight[:, 64:]).view_as(update)
+        if needs[2]:
+            d_weight = dw_p.sum(0).view(64, 128)
+        if needs[3]:
+            d_bias = d_z.sum(0)
+        if has_ln and needs[4]:
+            d_g = dg_p.sum(0)
+        if has_ln and needs[5]:
+            d_b = db_p.sum(0)
+        return d_input, d_update, d_weight, d_bias, d_g, d_b, None, None, None
+
+
+def combine(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False):
+    """``combine`` + shortcut of one layer (``ultra/layer.py:386-392``, ``ultra/model.py:126-127``) as fused HIP
+    kernels, differentiable: same forward as :func:`combine_forward`, fused backward."""
+    tensors = [t for t in (input, update, weight, bias, ln_weight, ln_bias) if t is not None]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        return _CombineFunction.apply(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
+    return combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
 
 
 class _RSPMMFunction(torch.autograd.Function):

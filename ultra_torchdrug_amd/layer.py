@@ -71,9 +71,9 @@ class _RelationalConvBase(nn.Module):
         update = self.message_and_aggregate(graph, input)
         if self._fusable(input, update):
             ln = self.layer_norm
-            return functional.combine_forward(input, update, self.linear.weight, self.linear.bias,
-                                              ln.weight if ln else None, ln.bias if ln else None,
-                                              ln.eps if ln else 1e-5, relu=self.activation is F.relu, shortcut=shortcut)
+            return functional.combine(input, update, self.linear.weight, self.linear.bias,
+                                      ln.weight if ln else None, ln.bias if ln else None,
+                                      ln.eps if ln else 1e-5, relu=self.activation is F.relu, shortcut=shortcut)
         output = self.combine(input, update)
         return output + input if shortcut else output
 
@@ -81,15 +81,14 @@ class _RelationalConvBase(nn.Module):
         return not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors if t is not None)
 
     def _fusable(self, input, update):
-        """The fused epilogue kernel covers the shipped layer shape: 64 -> 64, concat of 2, relu or no activation,
-        inference (autograd keeps the ATen ops)."""
+        """The fused epilogue kernels (forward and backward) cover the shipped layer shape: 64 -> 64, concat of 2,
+        relu or no activation; anything else runs the reference's ATen ops."""
         ln = self.layer_norm
         return (input.is_cuda and input.dtype == torch.float32 and input.shape == update.shape
                 and input.shape[-1] == 64 and self.output_dim == 64 and tuple(self.linear.weight.shape) == (64, 128)
                 and (self.activation is F.relu or not self.activation)
                 and (ln is None or (ln.elementwise_affine and ln.bias is not None))
-                and hasattr(functional, "combine_forward")
-                and self._no_grad(input, update, self.linear.weight, self.linear.bias))
+                and hasattr(functional, "combine"))
 
     # ---- O(E) definition, used for rotate / graphs that require grad (layer.py:52-109, :232-296) ---------
     def message(self, graph, input):
