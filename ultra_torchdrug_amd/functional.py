@@ -208,9 +208,10 @@ class _CombineFunction(torch.autograd.Function):
         needs = ctx.needs_input_grad
         d_input = d_update = d_weight = d_bias = d_g = d_b = None
         if needs[0]:
-            d_input = torch.mm(d_z, weight[:, :64]).view_as(input)
-            if shortcut:
-                d_input = d_input + grad_out.view_as(input)
+            if shortcut:        # d_input = grad_out + d_z . W[:, :64] in one GEMM call (beta = 1)
+                d_input = torch.addmm(grad_out.view(rows, 64), d_z, weight[:, :64]).view_as(input)
+            else:
+                d_input = torch.mm(d_z, weight[:, :64]).view_as(input)
         if needs[1]:
             d_update = torch.mm(d_z, weight[:, 64:]).view_as(update)
         if needs[2]:
@@ -237,8 +238,10 @@ class _RSPMMFunction(torch.autograd.Function):
     """Counterpart of torchdrug's ``RSPMM{Add,Min,Max}{Mul,Add}Function`` autograd classes."""
 
     @staticmethod
-    def forward(ctx, sparse, relation, input, csr, sum, mul):
-        out = rspmm_forward(csr, relation, input, sum, mul)
+    def forward(ctx, sparse, relation, input, csr, sum, mul, add_rows=None):
+        # add_rows (sum only): `update + boundary` of layer.py:156,358 inside the kernel; its gradient is grad_out
+        out = rspmm_forward(csr, relation, input, sum, mul, add_rows=add_rows)
+        ctx.has_add_rows = add_rows is not None
         ctx.csr, ctx.sum, ctx.mul = csr, sum, mul
         ctx.sparse_meta = None
         if sparse is not None and sparse.requires_grad:
@@ -258,7 +261,15 @@ class _RSPMMFunction(torch.autograd.Function):
             indices, shape = ctx.sparse_meta
             # duplicates of one triple all receive its gradient
             d_sparse = torch.sparse_coo_tensor(indices, d_w[ctx.csr.edge_of_input], shape)
-        return d_sparse, d_relation, d_input, None, None, None
+        d_add = output_grad if (ctx.has_add_rows and ctx.needs_input_grad[6]) else None
+        return d_sparse, d_relation, d_input, None, None, None, d_add
+
+
+def rspmm_sum_plus(sparse, relation, input, add_rows, mul="mul"):
+    """``generalized_rspmm(..., sum="add") + add_rows`` with the addition inside the kernel (differentiable)."""
+    csr, sparse_leaf = _as_relcsr(sparse)
+    _check_dense(csr, relation, input)
+    return _RSPMMFunction.apply(sparse_leaf, relation, input, csr, "add", mul, add_rows)
 
 
 def generalized_rspmm(sparse, relation, input, sum="add", mul="mul"):

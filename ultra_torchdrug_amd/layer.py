@@ -172,6 +172,8 @@ class _RelationalConvBase(nn.Module):
         if kind in ("sum", "mean"):
             if fuse_bound:
                 update = functional.rspmm_forward(adjacency, relation_input, input, "add", mul, add_rows=boundary)
+            elif bound and input.is_cuda and hasattr(functional, "rspmm_sum_plus"):
+                update = functional.rspmm_sum_plus(adjacency, relation_input, input, boundary, mul=mul)   # training
             else:
                 update = rspmm(adjacency, relation_input, input, sum="add", mul=mul)
                 if bound:
