@@ -252,12 +252,11 @@ def main():
             # the same first batch once more with the CPU oracle in place of the HIP operator (checker, not product)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle_ops import oracle_rspmm
-            from ultra_torchdrug_amd.relcsr import PIECE_LEN
             cpu_task = build_ultra(n_rel)
             cpu_task.load_state_dict({k: v.cpu() for k, v in task.state_dict().items()})
             cpu_task.preprocess(Graph(torch.from_numpy(triples), num_node=n_node, num_relation=n_rel),
                                 torch.from_numpy(fact_mask)).eval()
-            with torch.no_grad(), oracle_rspmm(PIECE_LEN):
+            with torch.no_grad(), oracle_rspmm(None):
                 batch_cpu = shard[:B].cpu()
                 pred_cpu = cpu_task.predict(batch_cpu)
                 ranks_cpu = cpu_task.get_ranking(pred_cpu, cpu_task.target(batch_cpu))

@@ -46,13 +46,33 @@ class OracleFunctional:
                                                        relcsr.rel_id.cpu().numpy(), w, n_dst, n_src, n_rel))
         return self._cache[key][1]
 
+    cpu_ok = True      # lets the layers route CPU tensors to `combine` below (the product itself is GPU-only)
+
+    def combine(self, input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False):
+        """Layer epilogue on the CPU: the oracle's C restatement (the HIP kernel's documented order) for inference,
+        the reference's own torch chain (layer.py:386-392, model.py:126-127) when autograd is needed."""
+        tensors = [t for t in (input, update, weight, bias, ln_weight, ln_bias) if t is not None]
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            out = torch.nn.functional.linear(torch.cat([input, update], dim=-1), weight, bias)
+            if ln_weight is not None:
+                out = torch.nn.functional.layer_norm(out, (64,), ln_weight, ln_bias, ln_eps)
+            if relu:
+                out = torch.relu(out)
+            return out + input if shortcut else out
+        out = O.combine_forward(input.detach().numpy(), update.detach().numpy(), weight.detach().numpy(),
+                                bias.detach().numpy(), None if ln_weight is None else ln_weight.detach().numpy(),
+                                None if ln_bias is None else ln_bias.detach().numpy(), ln_eps, relu, shortcut)
+        return torch.from_numpy(out).view_as(input)
+
     def generalized_rspmm(self, sparse, relation, input, sum="add", mul="mul"):
-        return _OracleRSPMM.apply(relation.contiguous(), input.contiguous(), self._csr(sparse), sum, mul, self.piece)
+        piece = sparse.piece_len if self.piece is None else self.piece       # None: each plan's own piece length
+        return _OracleRSPMM.apply(relation.contiguous(), input.contiguous(), self._csr(sparse), sum, mul, piece)
 
 
 @contextlib.contextmanager
-def oracle_rspmm(piece):
-    """Inside the context the layers aggregate with the CPU oracle (kernel summation order when piece > 0)."""
+def oracle_rspmm(piece=None):
+    """Inside the context the layers aggregate with the CPU oracle: ``piece=None`` -> the kernels' summation order
+    (every RelCSR's own ``piece_len``), ``piece=0`` -> the reference's strictly sequential order."""
     from ultra_torchdrug_amd import layer
     saved = layer.functional
     layer.functional = OracleFunctional(piece)

@@ -303,3 +303,31 @@ def test_inductive_and_multigraph_contexts():
             assert torch.isfinite(loss) and multi.split == gid
             assert int(batch[:, 2].max()) < multi.num_relation
     assert seen == {"0", "1"}
+
+
+def test_reference_checkpoint_layout_loads(tmp_path):
+    """util.py:233-276: {"model": state_dict (+ stray graph objects), "optimizer": ...}, non-strict load."""
+    from ultra_torchdrug_amd import checkpoint
+    from ultra_torchdrug_amd.task import build_ultra
+    torch.manual_seed(3)
+    src = build_ultra(237)
+    ref_state = {k: v.clone() for k, v in src.state_dict().items()}
+    ref_state["fact_graph"] = object()                      # what an old torchdrug checkpoint may still carry
+    ref_state["rel_graphs"] = ["not", "a", "tensor"]
+    path = tmp_path / "td_ultra_like.pth"
+    torch.save({"model": ref_state, "optimizer": {"state": {}, "param_groups": []}}, path)
+    torch.manual_seed(4)
+    dst = build_ultra(51)                                   # another dataset: weights do not depend on #relations
+    missing, unexpected = checkpoint.load_checkpoint(dst, str(path), map_location="cpu")
+    assert missing == [] and unexpected == []
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    # fix_reasoner keeps the current relation-specific weights (util.py:247-258)
+    torch.manual_seed(5)
+    other = build_ultra(51)
+    keep = other.state_dict()["rel_models.0.model.layers.0.relation.weight"].clone()
+    checkpoint.load_checkpoint(other, str(path), fix_reasoner=True, map_location="cpu")
+    assert torch.equal(other.state_dict()["rel_models.0.model.layers.0.relation.weight"], keep)
+    assert torch.equal(other.state_dict()["model.mlp.layers.0.weight"], src.state_dict()["model.mlp.layers.0.weight"])
+    saved = checkpoint.save_checkpoint(dst, str(tmp_path / "out.pth"))
+    assert set(saved["model"]) == set(src.state_dict())

@@ -38,12 +38,11 @@ def _near_tie_free(pred, target, mask, margin):
 
 @pytest.mark.parametrize("shape", ["S-tiny", (1200, 9000, 12)])
 def test_predict_scores_and_ranks_match_oracle_path(shape):
-    from ultra_torchdrug_amd.relcsr import PIECE_LEN
     task, triples = _build(shape)
     rng = np.random.default_rng(7)
     batch = torch.from_numpy(triples[rng.choice(len(triples), 16, replace=False)])
 
-    with torch.no_grad(), oracle_rspmm(PIECE_LEN):
+    with torch.no_grad(), oracle_rspmm(None):
         pred_cpu = task.predict(batch)
         mask_cpu, target_cpu = task.target(batch)
         rank_cpu = task.get_ranking(pred_cpu, (mask_cpu, target_cpu))
@@ -68,7 +67,6 @@ def test_predict_scores_and_ranks_match_oracle_path(shape):
 
 def test_training_step_gradients_match_oracle_path():
     """One fine-tuning step's loss and parameter gradients (rspmm fwd+bwd through both stacks)."""
-    from ultra_torchdrug_amd.relcsr import PIECE_LEN
     task, triples = _build("S-tiny")
     task.train()
     task.num_negative = 16
@@ -85,7 +83,7 @@ def test_training_step_gradients_match_oracle_path():
         grads = {k: p.grad.detach().cpu().clone() for k, p in task.named_parameters() if p.grad is not None}
         return loss.item(), grads, neg.cpu()
 
-    with oracle_rspmm(PIECE_LEN):
+    with oracle_rspmm(None):
         loss_cpu, grads_cpu, neg = run(torch.device("cpu"))
     task._strict_negative = lambda *a: neg.to(a[0].device)
     loss_gpu, grads_gpu, _ = run(torch.device("cuda:0"))
@@ -118,7 +116,6 @@ def test_inductive_zero_shot_inference_matches_oracle_path():
     split, ultra/task.py:525-634); HIP path vs the same model with the CPU oracle as operator."""
     from ultra_torchdrug_amd.data import synthetic_triples
     from ultra_torchdrug_amd.graph import Graph
-    from ultra_torchdrug_amd.relcsr import PIECE_LEN
     from ultra_torchdrug_amd.task import build_ultra
     tr, n1, r = synthetic_triples((400, 3000, 9), 11)
     te, n2, _ = synthetic_triples((700, 5000, 9), 12)
@@ -128,7 +125,7 @@ def test_inductive_zero_shot_inference_matches_oracle_path():
     g_te = Graph(torch.from_numpy(te), num_node=n2, num_relation=r)
     task.preprocess_inductive(g_tr, g_tr, g_te).eval().use("test")
     batch = torch.from_numpy(te[:16])
-    with torch.no_grad(), oracle_rspmm(PIECE_LEN):
+    with torch.no_grad(), oracle_rspmm(None):
         pred_cpu = task.predict(batch)
         rank_cpu = task.get_ranking(pred_cpu, task.target(batch))
     dev = torch.device("cuda:0")

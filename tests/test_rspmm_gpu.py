@@ -1,6 +1,6 @@
 """GPU parity: libultra_rspmm.so (through the C ABI / ctypes) against the CPU oracle on the same seeded inputs.
 
-Bars (fp32): with the oracle in the kernels' documented summation order (`piece=PIECE_LEN`) every element must
+Bars (fp32): with the oracle in the kernels' documented summation order (`piece = csr.piece_len`) every element must
 be IDENTICAL; against the strictly sequential reference order (`piece=0`) rows that were not split are identical
 and split rows (only the order of fp32 additions differs) agree to |diff| <= 1e-6 * S + 1e-6, where S is the
 same reduction over absolute values (the sum of |terms| of that output element): both orders are within
@@ -60,15 +60,14 @@ CASES = {
 @pytest.mark.parametrize("mul", MULS)
 def test_forward_matches_oracle(oracle, case, sum, mul):
     from ultra_torchdrug_amd import functional as UF
-    from ultra_torchdrug_amd.relcsr import PIECE_LEN
     kw, n, r, F = CASES[case]
     g = random_graph(seed=zlib.crc32(case.encode()) % 1000, n_node=n, n_rel=r, **kw)
     relation, x = _inputs(1, n, r, F)
     csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    csr = _relcsr(g, n, n, r)
+    PIECE_LEN = csr.piece_len
     want_kernel_order = oracle.rspmm_forward(csr_o, relation, x, sum, mul, piece=PIECE_LEN)
     want_sequential = oracle.rspmm_forward(csr_o, relation, x, sum, mul, piece=0)
-
-    csr = _relcsr(g, n, n, r)
     assert csr.n_edges == csr_o.n_edges
     dev = _dev()
     got = UF.generalized_rspmm(csr, torch.from_numpy(relation).to(dev), torch.from_numpy(x).to(dev), sum=sum, mul=mul)
@@ -98,7 +97,6 @@ def test_forward_matches_oracle(oracle, case, sum, mul):
 @pytest.mark.parametrize("mul", MULS)
 def test_backward_matches_oracle(oracle, case, sum, mul):
     from ultra_torchdrug_amd import functional as UF
-    from ultra_torchdrug_amd.relcsr import PIECE_LEN
     kw, n, r, F = CASES[case]
     kw = dict(kw, unique=True)   # min/max ties are only well defined on coalesced inputs; weights stay as given
     g = random_graph(seed=zlib.crc32(case.encode()) % 1000 + 7, n_node=n, n_rel=r, **kw)
@@ -106,12 +104,13 @@ def test_backward_matches_oracle(oracle, case, sum, mul):
     rng = np.random.default_rng(5)
     grad = rng.standard_normal((n, F)).astype(np.float32)
     csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    csr = _relcsr(g, n, n, r)
+    PIECE_LEN = csr.piece_len
     out_o = oracle.rspmm_forward(csr_o, relation, x, sum, mul, piece=PIECE_LEN)
     d_rel_k, d_x_k = oracle.rspmm_backward(csr_o, relation, x, out_o, grad, sum, mul, piece=PIECE_LEN)
     d_rel_s, d_x_s = oracle.rspmm_backward(csr_o, relation, x, out_o, grad, sum, mul, piece=0)
 
     dev = _dev()
-    csr = _relcsr(g, n, n, r)
     rel_t = torch.from_numpy(relation).to(dev).requires_grad_()
     x_t = torch.from_numpy(x).to(dev).requires_grad_()
     out = UF.generalized_rspmm(csr, rel_t, x_t, sum=sum, mul=mul)
@@ -227,8 +226,7 @@ def test_fb15k237_shape_properties(oracle):
     assert torch.equal(UF.generalized_rspmm(csr, relation, x1), o1)          # deterministic: run-to-run identical
     # oracle on the first 64 columns (one tile) of the whole graph
     csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], None, n, n, r)
-    from ultra_torchdrug_amd.relcsr import PIECE_LEN
-    want = oracle.rspmm_forward(csr_o, relation[:, :64].cpu().numpy(), x1[:, :64].cpu().numpy(), piece=PIECE_LEN)
+    want = oracle.rspmm_forward(csr_o, relation[:, :64].cpu().numpy(), x1[:, :64].cpu().numpy(), piece=csr.piece_len)
     assert np.array_equal(o1[:, :64].cpu().numpy(), want)
 
 
@@ -321,7 +319,6 @@ def test_wide_id_variants_match_oracle(oracle, case):
     """Big-graph kernel variants (node ids outside the packed word; relation tile in LDS or, when it does not fit,
     read through L2), forced on small graphs with `wide_ids=True`: forward and sum-backward, bit for bit."""
     from ultra_torchdrug_amd import RelCSR, functional as UF
-    from ultra_torchdrug_amd.relcsr import PIECE_LEN
     kw, n, r, F = CASES[case]
     g = random_graph(seed=zlib.crc32(case.encode()) % 1000 + 3, n_node=n, n_rel=r, **dict(kw, unique=True))
     relation, x = _inputs(8, n, r, F)
@@ -331,6 +328,7 @@ def test_wide_id_variants_match_oracle(oracle, case):
     t = lambda a: torch.from_numpy(a).to(dev)
     csr = RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), None if g["w"] is None else t(g["w"]), n, n, r, wide_ids=True)
     assert csr.fwd.packed_src_shift == 32 and csr.by_src.packed_src_shift == 32
+    PIECE_LEN = csr.piece_len
     for s in SUMS:
         for m in MULS:
             want = oracle.rspmm_forward(csr_o, relation, x, s, m, piece=PIECE_LEN)

@@ -26,15 +26,11 @@ def main():
     import ultra_torchdrug_amd as U
     from ultra_torchdrug_amd import _lib, relcsr, functional as UF
     from ultra_torchdrug_amd.data import synthetic_kg
-    if args.piece:
-        relcsr.PIECE_LEN = args.piece
-    if args.chunk:
-        relcsr.CHUNK_EDGES = args.chunk
     lib = U.require_library()
     lib.ultra_rspmm_force_general_path(1 if args.general else 0)
     dev = torch.device("cuda:0")
     g = synthetic_kg(args.workload, device=dev).undirected(add_inverse=True)
-    opts = dict(piece_len=relcsr.PIECE_LEN, chunk_edges=relcsr.CHUNK_EDGES)
+    opts = dict(piece_len=args.piece, chunk_edges=args.chunk)      # None: chosen from the edge count
     csr = U.RelCSR.from_edge_list(g.edge_list, g.edge_weight, g.num_node, g.num_relation, **opts)
     F = args.batch * 64
     gen = torch.Generator(device="cpu").manual_seed(0)

@@ -84,7 +84,8 @@ class _RelationalConvBase(nn.Module):
         """The fused epilogue kernels (forward and backward) cover the shipped layer shape: 64 -> 64, concat of 2,
         relu or no activation; anything else runs the reference's ATen ops."""
         ln = self.layer_norm
-        return (input.is_cuda and input.dtype == torch.float32 and input.shape == update.shape
+        on_device = input.is_cuda or getattr(functional, "cpu_ok", False)   # cpu_ok: only the tests' oracle stand-in
+        return (on_device and input.dtype == torch.float32 and input.shape == update.shape
                 and input.shape[-1] == 64 and self.output_dim == 64 and tuple(self.linear.weight.shape) == (64, 128)
                 and (self.activation is F.relu or not self.activation)
                 and (ln is None or (ln.elementwise_affine and ln.bias is not None))

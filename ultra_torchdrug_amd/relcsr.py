@@ -27,9 +27,19 @@ import torch
 
 from . import _lib
 
-CHUNK_EDGES = 64     # target edges per whole-row chunk
 CHUNK_ROWS = 64      # at most this many rows per chunk (bounds the work of runs of empty rows)
-PIECE_LEN = 128      # rows longer than this are cut into pieces of this many edges
+
+
+def auto_sizes(n_edges):
+    """(chunk_edges, piece_len) for a graph with ``n_edges`` coalesced edges.  Bigger chunks mean fewer pieces, less
+    fix-up traffic and longer runs of the branch-free batch path, but a wave needs several chunks per column tile to
+    stay busy (512 waves share a tile on an MI355X): measured best on S-codexs (66 k edges) 32 / 128, on S-wn18rr
+    (174 k), S-fb15k237 (544 k) and S-codexm 128 / 512 (tools/kbench.py --chunk --piece)."""
+    chunk = 128 if n_edges >= 150_000 else (64 if n_edges >= 100_000 else 32)
+    return chunk, 4 * chunk
+
+
+CHUNK_EDGES, PIECE_LEN = auto_sizes(0)    # the sizes small graphs get (kept as names for explicit callers / tests)
 PACK_SLACK = 16      # readable words after the last edge of `packed` / `weight` (whole-batch loads)
 _INT32_MAX = 2 ** 31 - 1
 
@@ -188,8 +198,8 @@ def _sum_duplicates(weight, first, count):
 class RelCSR:
     """Coalesced relational adjacency of shape ``(n_dst, n_src, n_rel)`` plus its reduction plans."""
 
-    def __init__(self, dst, src, rel, weight, n_dst, n_src, n_rel, chunk_edges=CHUNK_EDGES, chunk_rows=CHUNK_ROWS,
-                 piece_len=PIECE_LEN, balance=True, wide_ids=False):
+    def __init__(self, dst, src, rel, weight, n_dst, n_src, n_rel, chunk_edges=None, chunk_rows=CHUNK_ROWS,
+                 piece_len=None, balance=True, wide_ids=False):
         """``dst/src/rel``: int64 tensors [E] (any order, duplicates allowed); ``weight``: fp32 [E] or None (ones)."""
         dev = dst.device
         dst, src, rel = dst.long(), src.long(), rel.long()
@@ -201,8 +211,8 @@ class RelCSR:
         if float(n_dst) * float(n_src) * float(max(n_rel, 1)) >= 2.0 ** 62:
             raise ValueError("adjacency too large for a 64-bit sort key")
         self.shape = (n_dst, n_src, n_rel)
-        self._opts = dict(chunk_edges=chunk_edges, chunk_rows=chunk_rows, piece_len=piece_len, balance=balance,
-                          wide_ids=wide_ids)
+        self._requested = (chunk_edges, piece_len)
+        self._opts = dict(chunk_rows=chunk_rows, balance=balance, wide_ids=wide_ids)
         if weight is None:
             weight = torch.ones(dst.shape[0], dtype=torch.float32, device=dev)
         weight = weight.to(torch.float32)
@@ -227,6 +237,12 @@ class RelCSR:
         self.unit_weight = bool((w_merged == 1).all().item()) if w_merged.numel() else True
         self.weight = w_merged
         self.n_edges = int(dst.shape[0])
+        # chunk / piece sizes: explicit, or chosen from the coalesced edge count; ONE pair for all three plans, and
+        # `piece_len` is the summation-order parameter the oracle needs (oracle `piece`)
+        auto_chunk, auto_piece = auto_sizes(self.n_edges)
+        self.chunk_edges = int(self._requested[0] or auto_chunk)
+        self.piece_len = int(self._requested[1] or (auto_piece if self._requested[0] is None else 4 * self.chunk_edges))
+        self._opts.update(chunk_edges=self.chunk_edges, piece_len=self.piece_len)
         self._fwd = self._by_src = self._by_rel = None
 
     # ------------------------------------------------------------------ constructors
@@ -296,6 +312,7 @@ class RelCSR:
         one triple add up, as ``coalesce()`` would.  Shares the sorted index arrays and chunk schedules."""
         other = RelCSR.__new__(RelCSR)
         other.shape, other._opts = self.shape, self._opts
+        other.chunk_edges, other.piece_len = self.chunk_edges, self.piece_len
         other.dst, other.src, other.rel_id = self.dst, self.src, self.rel_id
         other.edge_of_input, other.n_edges = self.edge_of_input, self.n_edges
         w = torch.zeros(self.n_edges, dtype=torch.float32, device=self.device)
