@@ -175,6 +175,17 @@ int ultra_combine_backward_f32(const float *input, const float *update, const fl
                                float *d_ln_bias_partial, float *d_weight_partial, int64_t rows, int64_t dim,
                                void *stream);
 
+
+/*
+ * out[rows, out_dim] = relu?( input[rows, in_dim] . weight[out_dim, in_dim]^T + bias ) in a documented summation order
+ * (k-ordered fmaf chain from the bias: k = 0, in_dim/2, 1, in_dim/2 + 1, ...; for out_dim == 1: k ascending), so that
+ * the small nn.Linear layers around the Bellman-Ford stacks -- relation projection 64 -> 64 -> 64
+ * (/root/reference/ultra/layer.py:228,318-319) and score head 128 -> 128 -> 1 (ultra/model.py:53,193) -- give the same
+ * bits on the GPU and in the CPU oracle.  Shapes: (64, 64), (128, 128), (in_dim % 4 == 0, 1).  Forward only.
+ */
+int ultra_linear_forward_f32(const float *input, const float *weight, const float *bias, float *out, int64_t rows,
+                             int64_t in_dim, int64_t out_dim, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,7 +41,8 @@ def lib():
         build()
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_abi_version.restype = ctypes.c_int
-        for name in ("oracle_rspmm_forward", "oracle_rspmm_backward", "oracle_filtered_rank", "oracle_combine_forward"):
+        for name in ("oracle_rspmm_forward", "oracle_rspmm_backward", "oracle_filtered_rank", "oracle_combine_forward",
+                     "oracle_linear_forward"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -208,3 +209,19 @@ def combine_forward(input, update, weight, bias, gamma=None, beta=None, eps=1e-5
     if rc:
         raise RuntimeError("oracle_combine_forward failed")
     return out
+
+
+def linear_forward(input, weight, bias, relu=False):
+    """The small dense layers (``ultra/layer.py:228,318-319``, ``ultra/model.py:53,193``) in the kernels' documented order."""
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    bias = np.ascontiguousarray(bias, dtype=np.float32)
+    out_dim, in_dim = weight.shape
+    x = np.ascontiguousarray(input, dtype=np.float32)
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, in_dim)
+    out = np.empty((x2.shape[0], out_dim), dtype=np.float32)
+    rc = lib().oracle_linear_forward(_p(x2), _p(weight), _p(bias), _p(out), _i64(x2.shape[0]), _i64(in_dim),
+                                     _i64(out_dim), int(bool(relu)))
+    if rc:
+        raise RuntimeError("oracle_linear_forward failed")
+    return out.reshape(lead + (out_dim,))

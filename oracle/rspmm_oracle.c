@@ -312,3 +312,33 @@ int oracle_combine_forward(const float *input, const float *update, const float 
     }
     return 0;
 }
+
+/*
+ * relu?( input . weight^T + bias ) for the small dense layers (relation projection, ultra/layer.py:228,318-319; score
+ * head, ultra/model.py:53,193) in the HIP library's documented order:
+ *   out_dim > 1 : acc = bias[o]; for s in 0..K/2-1: acc = fmaf(in[s], W[o][s], acc); acc = fmaf(in[K/2+s], W[o][K/2+s], acc)
+ *   out_dim == 1: acc = bias[0]; for k ascending: acc = fmaf(in[k], W[0][k], acc)
+ */
+int oracle_linear_forward(const float *input, const float *weight, const float *bias, float *out, int64_t rows,
+                          int64_t in_dim, int64_t out_dim, int relu) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        const float *in = input + r * in_dim;
+        for (int64_t o = 0; o < out_dim; ++o) {
+            const float *w = weight + o * in_dim;
+            float acc = bias[o];
+            if (out_dim == 1) {
+                for (int64_t k = 0; k < in_dim; ++k) acc = fmaf(in[k], w[k], acc);
+            } else {
+                const int64_t half = in_dim / 2;
+                for (int64_t s = 0; s < half; ++s) {
+                    acc = fmaf(in[s], w[s], acc);
+                    acc = fmaf(in[half + s], w[half + s], acc);
+                }
+            }
+            if (relu) acc = acc > 0.0f ? acc : 0.0f;
+            out[r * out_dim + o] = acc;
+        }
+    }
+    return 0;
+}

@@ -384,3 +384,25 @@ def test_fused_combine_backward_matches_autograd_of_the_reference_formulation(ro
         scale = w.abs().max().item() + 1e-12
         err = (g.grad.cpu().double() - w).abs().max().item()
         assert err <= 2e-5 * scale + 1e-6, "%s: err %.3g vs scale %.3g" % (name, err, scale)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, True), (64, 64, False), (128, 128, True), (128, 1, False)])
+@pytest.mark.parametrize("rows", [1, 37, 7584, 232656])
+def test_documented_order_linear_matches_oracle_and_torch(oracle, shape, rows):
+    """ultra_linear_forward_f32 (relation projection 64->64->64, score head 128->128->1): identical bits to the
+    oracle's fmaf chain, and within fp32 tolerance of nn.Linear (the reference's formulation)."""
+    from ultra_torchdrug_amd import functional as UF
+    k, n, relu = shape
+    dev = _dev()
+    gen = torch.Generator(device="cpu").manual_seed(rows + k)
+    x = torch.randn(rows, k, generator=gen)
+    lin = torch.nn.Linear(k, n)
+    with torch.no_grad():
+        got = UF.linear_forward(x.to(dev), lin.weight.to(dev), lin.bias.to(dev), relu=relu).cpu()
+        ref = lin(x)
+        if relu:
+            ref = torch.relu(ref)
+    torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
+    sub = slice(0, min(rows, 4000))
+    want = oracle.linear_forward(x[sub].numpy(), lin.weight.detach().numpy(), lin.bias.detach().numpy(), relu)
+    assert np.array_equal(got[sub].numpy(), want)

@@ -1226,3 +1226,4 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
 }  // extern "C"
 
 #include "combine_train.inc"
+#include "dense.inc"

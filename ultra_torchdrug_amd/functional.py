@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -167,6 +167,29 @@ def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, l
             ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
             ln_bias.contiguous().data_ptr() if ln_weight is not None else None,
             float(ln_eps), int(bool(relu)), int(bool(shortcut)), out.data_ptr(), rows, 64, _stream()))
+    return out
+
+
+def linear_supported(in_dim, out_dim):
+    """Shapes ``libultra_rspmm`` computes in its documented order: the relation projection and the score head."""
+    return (in_dim, out_dim) in ((64, 64), (128, 128)) or (out_dim == 1 and in_dim % 4 == 0)
+
+
+def linear_forward(input, weight, bias, relu=False):
+    """``relu?(F.linear(input, weight, bias))`` (forward only) in the library's documented summation order: the
+    small dense layers of ``ultra/layer.py:228,318-319`` and ``ultra/model.py:53,193``."""
+    out_dim, in_dim = weight.shape
+    if not linear_supported(in_dim, out_dim) or input.shape[-1] != in_dim or bias is None:
+        raise RuntimeError("linear_forward: unsupported shape %s x %s" % (tuple(input.shape), tuple(weight.shape)))
+    if any(t.dtype != torch.float32 or not t.is_cuda or t.device != input.device for t in (input, weight, bias)):
+        raise RuntimeError("linear_forward needs fp32 tensors on one HIP device (no CPU fallback)")
+    x = input.contiguous()
+    rows = x.numel() // in_dim
+    out = torch.empty(tuple(input.shape[:-1]) + (out_dim,), dtype=torch.float32, device=input.device)
+    lib = _lib.load()
+    with torch.cuda.device(input.device):
+        _lib.check(lib.ultra_linear_forward_f32(x.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                                                out.data_ptr(), rows, in_dim, out_dim, int(bool(relu)), _stream()))
     return out
 
 

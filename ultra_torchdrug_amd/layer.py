@@ -31,11 +31,27 @@ class MLP(nn.Module):
         self.activation = getattr(F, activation) if isinstance(activation, str) else activation
         self.layers = nn.ModuleList(nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(len(self.dims) - 1))
 
+    def _library_linear(self, layer, x, relu):
+        """Inference on the GPU: the layer runs in libultra_rspmm's documented summation order (bit-identical to the
+        CPU oracle); training and unsupported shapes keep nn.Linear."""
+        on_device = x.is_cuda or getattr(functional, "cpu_ok", False)
+        if not (on_device and hasattr(functional, "linear_forward") and x.dtype == torch.float32
+                and layer.bias is not None and functional.linear_supported(layer.in_features, layer.out_features)):
+            return None
+        if torch.is_grad_enabled() and (x.requires_grad or layer.weight.requires_grad):
+            return None
+        return functional.linear_forward(x, layer.weight, layer.bias, relu=relu)
+
     def forward(self, input):
         layer_input = input
         for i, layer in enumerate(self.layers):
-            hidden = layer(layer_input)
-            if i < len(self.layers) - 1 and self.activation:
+            act = i < len(self.layers) - 1 and bool(self.activation)
+            fused_relu = act and self.activation is F.relu
+            hidden = self._library_linear(layer, layer_input, fused_relu)
+            if hidden is None:
+                hidden = layer(layer_input)
+                fused_relu = False
+            if act and not fused_relu:
                 hidden = self.activation(hidden)
             if self.short_cut and hidden.shape == layer_input.shape:
                 hidden = hidden + layer_input
