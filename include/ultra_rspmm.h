@@ -186,6 +186,17 @@ int ultra_combine_backward_f32(const float *input, const float *update, const fl
 int ultra_linear_forward_f32(const float *input, const float *weight, const float *bias, float *out, int64_t rows,
                              int64_t in_dim, int64_t out_dim, int relu, void *stream);
 
+
+/*
+ * Score head of full-batch evaluation, fused:  out[b, n] = w2 . relu(W1 . cat[hidden[n, b, :], query[b, :]] + b1) + b2
+ * replaces cat (/root/reference/ultra/model.py:134-138), transpose + gather of all candidate tails (:177-183, the
+ * identity permutation when every entity is a candidate: ultra/task.py:249-253) and the 128 -> 128 -> 1 mlp (:193).
+ * hidden [n_node, batch, 64], query [batch, 64], w1 [128, 128], b1 [128], w2 [128], b2 [1], out [batch, n_node].
+ * Same summation order as ultra_linear_forward_f32 (128, 128, relu) followed by (128, 1): bit-identical results.
+ */
+int ultra_score_forward_f32(const float *hidden, const float *query, const float *w1, const float *b1, const float *w2,
+                            const float *b2, float *out, int64_t n_node, int64_t batch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

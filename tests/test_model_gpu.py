@@ -142,3 +142,22 @@ def test_inductive_zero_shot_inference_matches_oracle_path():
     mask, target = task.target(batch.to(dev))
     safe = _near_tie_free(pred_cpu, target.cpu(), mask.cpu(), 2 * diff + 1e-7)
     assert torch.equal(rank_gpu.cpu()[safe], rank_cpu[safe]) and safe.float().mean() > 0.8
+
+
+def test_fused_score_head_equals_unfused_path():
+    """ultra_score_forward_f32 vs cat + gather + linear(128,128,relu) + linear(128,1) of the same library."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for n_node, batch in [(1, 1), (37, 3), (1000, 16), (14541, 16)]:
+        hidden = torch.randn(n_node, batch, 64, generator=gen).to(dev)
+        query = torch.randn(batch, 64, generator=gen).to(dev)
+        l1, l2 = torch.nn.Linear(128, 128).to(dev), torch.nn.Linear(128, 1).to(dev)
+        with torch.no_grad():
+            fused = UF.score_all_entities(hidden, query, l1.weight, l1.bias, l2.weight, l2.bias)
+            feature = torch.cat([hidden, query.expand(n_node, -1, -1)], dim=-1).transpose(0, 1).contiguous()
+            h = UF.linear_forward(feature, l1.weight, l1.bias, relu=True)
+            plain = UF.linear_forward(h, l2.weight, l2.bias).squeeze(-1)
+            ref = l2(torch.relu(l1(feature))).squeeze(-1)
+        assert torch.equal(fused, plain)
+        torch.testing.assert_close(fused, ref, rtol=2e-5, atol=2e-5)

@@ -54,6 +54,7 @@ EXPORTS = (
     "ultra_combine_backward_waves",
     "ultra_combine_backward_f32",
     "ultra_linear_forward_f32",
+    "ultra_score_forward_f32",
 )
 
 _lib = None
@@ -116,6 +117,8 @@ def load():
     lib.ultra_combine_backward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, vp, vp, vp, vp, vp, i64, i64, vp]
     lib.ultra_linear_forward_f32.restype = i32
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
+    lib.ultra_score_forward_f32.restype = i32
+    lib.ultra_score_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
     if lib.ultra_rspmm_abi_version() != ABI_VERSION:
         raise UltraLibraryError("ABI mismatch: library %d, binding %d" % (lib.ultra_rspmm_abi_version(), ABI_VERSION))
     _lib = lib

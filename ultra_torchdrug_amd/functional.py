@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -190,6 +190,25 @@ def linear_forward(input, weight, bias, relu=False):
     with torch.cuda.device(input.device):
         _lib.check(lib.ultra_linear_forward_f32(x.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
                                                 out.data_ptr(), rows, in_dim, out_dim, int(bool(relu)), _stream()))
+    return out
+
+
+def score_all_entities(hidden, query, w1, b1, w2, b2):
+    """Score head over ALL entities, forward only: ``hidden`` ``(N, B, 64)``, ``query`` ``(B, 64)`` ->  ``(B, N)``
+    scores ``mlp(cat[hidden, query])`` (``ultra/model.py:134-138,177-193`` with every entity as candidate tail)."""
+    n_node, batch, dim = hidden.shape
+    if dim != 64 or tuple(query.shape) != (batch, 64) or tuple(w1.shape) != (128, 128) or w2.numel() != 128:
+        raise RuntimeError("score_all_entities handles the 64-d model with a 128 -> 128 -> 1 head")
+    tensors = (hidden, query, w1, b1, w2, b2)
+    if any(t.dtype != torch.float32 or not t.is_cuda or t.device != hidden.device for t in tensors):
+        raise RuntimeError("score_all_entities needs fp32 tensors on one HIP device (no CPU fallback)")
+    out = torch.empty(batch, n_node, dtype=torch.float32, device=hidden.device)
+    lib = _lib.load()
+    with torch.cuda.device(hidden.device):
+        _lib.check(lib.ultra_score_forward_f32(hidden.contiguous().data_ptr(), query.contiguous().data_ptr(),
+                                               w1.contiguous().data_ptr(), b1.contiguous().data_ptr(),
+                                               w2.contiguous().data_ptr(), b2.contiguous().data_ptr(), out.data_ptr(),
+                                               n_node, batch, _stream()))
     return out
 
 

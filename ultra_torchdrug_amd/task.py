@@ -175,11 +175,13 @@ class KnowledgeGraphCompletion(nn.Module):
             for neg_index in all_index.split(num_negative):
                 r_index = pos_r_index.unsqueeze(-1).expand(-1, len(neg_index))
                 h_index, t_index = torch.meshgrid(pos_h_index, neg_index, indexing="ij")
-                t_preds.append(self.model(self.fact_graph, rel_inputs, h_index, t_index, r_index))
+                t_preds.append(self.model(self.fact_graph, rel_inputs, h_index, t_index, r_index,
+                                          all_entities=len(neg_index) == self.num_entity))
             for neg_index in all_index.split(num_negative):
                 r_index = pos_r_index.unsqueeze(-1).expand(-1, len(neg_index))
                 t_index, h_index = torch.meshgrid(pos_t_index, neg_index, indexing="ij")
-                h_preds.append(self.model(self.fact_graph, rel_inputs, h_index, t_index, r_index))
+                h_preds.append(self.model(self.fact_graph, rel_inputs, h_index, t_index, r_index,
+                                          all_entities=len(neg_index) == self.num_entity))
             return torch.stack([torch.cat(t_preds, dim=-1), torch.cat(h_preds, dim=-1)], dim=1)   # (B, 2, N)
 
         neg_index = self._strict_negative(pos_h_index, pos_t_index, pos_r_index)    # training
