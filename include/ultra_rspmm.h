@@ -76,6 +76,10 @@ typedef struct ultra_segments {
     /*   node_a (which then carries 16 readable words of slack after the last edge)                      */
     const uint32_t *packed;
     int64_t packed_src_shift;
+    /* optional hot-row cache (n_hot > 0): the node field of `packed` then holds the cache slot (< n_hot) for   */
+    /* the n_hot most frequently gathered nodes and n_hot + node id for all others                               */
+    int64_t n_hot;
+    const int32_t *hot_nodes;  /* [n_hot] */
 } ultra_segments;
 
 int ultra_rspmm_abi_version(void);

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.ultra_rspmm_abi_version() == 1
     assert lib.ultra_rspmm_status_string(1).decode().startswith("unknown sum/mul")
     import ctypes
-    assert ctypes.sizeof(_lib.UltraSegments) == 15 * 8          # struct layout of the header
+    assert ctypes.sizeof(_lib.UltraSegments) == 17 * 8          # struct layout of the header
 
 
 def test_operator_rejects_cpu_tensors_and_bad_names():
@@ -98,7 +98,11 @@ def test_relcsr_matches_oracle_coalesce_and_covers_everything(oracle, kw):
         if seg.packed is not None:                                    # packed words decode to the plain arrays
             w = seg.packed.numpy().astype(np.int64)[:seg.n_edges] & 0xFFFFFFFF
             sh = seg.packed_src_shift
-            assert np.array_equal(w >> sh, seg.node_a.numpy()[:seg.n_edges])
+            field = w >> sh
+            if seg.n_hot:                                             # hot-row cache: slot, or n_hot + node id
+                hot = seg.hot_nodes.numpy()
+                field = np.where(field < seg.n_hot, hot[np.minimum(field, seg.n_hot - 1)], field - seg.n_hot)
+            assert np.array_equal(field, seg.node_a.numpy()[:seg.n_edges])
             if seg.node_b is None:
                 assert np.array_equal((w >> 8) & ((1 << (sh - 8)) - 1), seg.rel.numpy())
             else:

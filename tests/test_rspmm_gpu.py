@@ -406,3 +406,29 @@ def test_documented_order_linear_matches_oracle_and_torch(oracle, shape, rows):
     sub = slice(0, min(rows, 4000))
     want = oracle.linear_forward(x[sub].numpy(), lin.weight.detach().numpy(), lin.bias.detach().numpy(), relu)
     assert np.array_equal(got[sub].numpy(), want)
+
+
+def test_hot_row_cache_variant_matches_plain_variant(oracle):
+    """Plans with and without the LDS hot-row cache (the n_hot most gathered nodes) give identical forward and
+    sum-backward results, equal to the oracle."""
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    n, r, F = 3000, 40, 128
+    g = random_graph(seed=31, n_node=n, n_edge=120000, n_rel=r, skew=True, unique=True, weights=True)
+    relation, x = _inputs(9, n, r, F)
+    grad = np.random.default_rng(4).standard_normal((n, F)).astype(np.float32)
+    dev = _dev()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    hot = RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), t(g["w"]), n, n, r, hot_cache=True)
+    cold = RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), t(g["w"]), n, n, r)
+    assert hot.fwd.n_hot >= 16 and hot.by_src.n_hot >= 16 and cold.fwd.n_hot == 0
+    csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    for s in SUMS:
+        for m in MULS:
+            a = UF.rspmm_forward(hot, t(relation), t(x), s, m)
+            b = UF.rspmm_forward(cold, t(relation), t(x), s, m)
+            assert torch.equal(a, b), (s, m)
+            assert _same(a.cpu().numpy(), oracle.rspmm_forward(csr_o, relation, x, s, m, piece=hot.piece_len))
+    for m in MULS:
+        da, ra = UF.rspmm_backward(hot, t(relation), t(x), None, t(grad), "add", m)
+        db, rb = UF.rspmm_backward(cold, t(relation), t(x), None, t(grad), "add", m)
+        assert torch.equal(da, db) and torch.equal(ra, rb)

@@ -33,6 +33,8 @@ class UltraSegments(ctypes.Structure):
         ("piece_len", ctypes.c_int64),
         ("packed", ctypes.c_void_p),
         ("packed_src_shift", ctypes.c_int64),
+        ("n_hot", ctypes.c_int64),
+        ("hot_nodes", ctypes.c_void_p),
     ]
 
 

@@ -287,6 +287,8 @@ struct PParams {
     uint32_t gather2_bytes;
     uint32_t relation_bytes;
     int n_gather_rows;
+    const int32_t *hot_nodes;   // VAR 4: [n_hot] node ids whose rows are cached in LDS
+    int n_hot;
     uint32_t row_bytes;
     uint32_t src_shift;
     uint32_t rel_mask;       // ((1 << bitsR) - 1) << 8
@@ -304,12 +306,17 @@ struct PParams {
 // VAR 2: big graphs -- ids do not fit one word: word = row delta | relation << 8, the node id comes from the plan's
 //        node_a array (second scalar load per batch); relation row through a buffer load (table too big for LDS).
 // VAR 3: as 2 with the relation tile in LDS.
+// VAR 4: as 0, plus a software-managed cache of HOT gathered rows in the LDS left over next to the relation tile: the
+//        plan lists the n_hot most frequently gathered nodes (KGs are heavy-tailed: the 140 hottest sources of the
+//        FB15k237-shaped graph feed 49 % of its edges); the word's node field holds the cache slot for those and
+//        n_hot + node for the rest, so a hot edge costs a ds_read_b32 instead of a trip through TA / L2.
 template <int KIND, int SUM, int MUL, bool UNIT_W, int VAR>
 __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
     constexpr bool X_LDS = (VAR == 1);
-    constexpr bool BIG = (VAR >= 2);
+    constexpr bool BIG = (VAR == 2 || VAR == 3);
     constexpr bool REL_GLOBAL = (VAR == 2);
-    static_assert(VAR == 0 || KIND != KIND_DREL, "variants 1-3 are for the single-gather kinds");
+    constexpr bool HOT = (VAR == 4);
+    static_assert(VAR == 0 || KIND != KIND_DREL, "variants 1-4 are for the single-gather kinds");
     static_assert(KIND == KIND_FWD || SUM == ULTRA_SUM_ADD, "packed path: forward, or the backward of sum-aggregation");
     constexpr int RED = (KIND == KIND_FWD) ? SUM : ULTRA_SUM_ADD;
     // forward / d_input: second operand = relation row (LDS).  d_relation (rows = relations): second operand =
@@ -355,15 +362,31 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                 lds_x[i] = (c < F) ? p.gather[(long long)r * F + c] : 0.0f;
             }
         }
+        if constexpr (HOT) {   // hot-row cache: the tile segments of the plan's hot nodes
+            const int total = p.n_hot * kTile;
+            for (int i = threadIdx.x; i < total; i += kBlock) {
+                const long long r = p.hot_nodes[i >> 6];
+                const long long c = (long long)tile * kTile + (i & 63);
+                lds_x[i] = (c < F) ? p.gather[r * F + c] : 0.0f;
+            }
+        }
         if (threadIdx.x == 0) *ticket = 0;
         __syncthreads();
         const char *lds_lane = reinterpret_cast<const char *>(lds_rel) + lane * 4;
         const char *lds_x_lane = reinterpret_cast<const char *>(lds_x) + lane * 4;
         // one gather: a 256-B row segment of `gather`, from LDS (X_LDS) or through a buffer load with a scalar offset
         auto gather_one = [&](uint32_t word) -> float {
-            if constexpr (X_LDS) return *reinterpret_cast<const float *>(lds_x_lane + ((word >> p.src_shift) << 8));
-            else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rsrc, voff, (word >> p.src_shift) * p.row_bytes, 0));
+            if constexpr (X_LDS) {
+                return *reinterpret_cast<const float *>(lds_x_lane + ((word >> p.src_shift) << 8));
+            } else if constexpr (HOT) {
+                const uint32_t g = word >> p.src_shift;       // wave-uniform: a scalar branch
+                if (g < (uint32_t)p.n_hot) return *reinterpret_cast<const float *>(lds_x_lane + (g << 8));
+                return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     rsrc, voff, (g - (uint32_t)p.n_hot) * p.row_bytes, 0));
+            } else {
+                return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     rsrc, voff, (word >> p.src_shift) * p.row_bytes, 0));
+            }
         };
 
         auto store_row = [&](int r, float v) {
@@ -866,6 +889,7 @@ int launch_packed_w(const PParams &p, bool unit_w, int var, int grid, size_t lds
         ULTRA_VAR(1)
         ULTRA_VAR(2)
         ULTRA_VAR(3)
+        ULTRA_VAR(4)
     }
     ULTRA_VAR(0)
 #undef ULTRA_VAR
@@ -994,6 +1018,14 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
             if (big) {
                 var = (needs_rel && !rel_fits) ? 2 : 3;
                 if (var == 2) lds_bytes = 0;
+            } else if (seg->n_hot > 0) {
+                // the plan's words address a hot-row cache: its rows must fit next to the relation tile
+                const size_t hot_bytes = (size_t)seg->n_hot * kTile * sizeof(float);
+                if (lds_bytes + hot_bytes > (size_t)kMaxLdsBytes) return ULTRA_ERR_BAD_SHAPE;
+                var = 4;
+                lds_bytes += hot_bytes;
+                q.hot_nodes = seg->hot_nodes;
+                q.n_hot = (int)seg->n_hot;
             } else if ((KIND != KIND_DREL) && !g_no_x_lds && gather_rows > 0 &&
                        lds_bytes + lds_x_bytes <= (size_t)kMaxLdsBytes) {
                 var = 1;

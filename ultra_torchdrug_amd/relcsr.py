@@ -41,6 +41,9 @@ def auto_sizes(n_edges):
 
 CHUNK_EDGES, PIECE_LEN = auto_sizes(0)    # the sizes small graphs get (kept as names for explicit callers / tests)
 PACK_SLACK = 16      # readable words after the last edge of `packed` / `weight` (whole-batch loads)
+LDS_TABLE_BYTES = 156 * 1024 - 16    # LDS the kernels give to the relation tile + hot-row cache (csrc: kMaxLdsBytes)
+HOT_MAX = 512        # at most this many cached rows
+HOT_MIN_COVERAGE = 0.2   # build a hot-row cache only if it serves at least this fraction of the gathers
 _INT32_MAX = 2 ** 31 - 1
 
 
@@ -48,7 +51,7 @@ class Segments:
     """One reduction plan; owns the device tensors and the ``ultra_segments`` struct pointing at them."""
 
     def __init__(self, row, node_a, node_b, rel, weight, n_rows, chunk_edges=CHUNK_EDGES, chunk_rows=CHUNK_ROWS,
-                 piece_len=PIECE_LEN, balance=True, wide_ids=False):
+                 piece_len=PIECE_LEN, balance=True, wide_ids=False, lds_rel_rows=0, n_gather_rows=0, hot_cache=False):
         """``wide_ids`` forces the big-graph word layout (node ids outside the packed word) even when they would fit
         -- used by tests to exercise that kernel variant on small graphs."""
         n_edges = int(row.shape[0])
@@ -76,10 +79,32 @@ class Segments:
         n_a = int(node_a.max()) + 1 if n_edges else 1
         # d_relation plan (node_b given): the row IS the relation, no relation field; the word holds node_a only
         bits_rel = 0 if node_b is not None else max((n_rel - 1).bit_length(), 1)
+        # hot-row cache (forward / d_input plans of KG-sized graphs): the most frequently gathered nodes, as many as fit
+        # in LDS next to the relation tile -- unless the whole gathered matrix fits there anyway (relation graphs).
+        # OFF by default: measured SLOWER on MI355X (S-fb15k237 forward 193 -> 250 us, S-wn18rr 122 -> 186 us): the
+        # per-edge scalar branch breaks the 8-deep load batches and an LDS read is no cheaper than an L1-hit gather
+        # in this instruction-bound loop; kept (tested, bit-identical) as a tuning switch.
+        self.hot_nodes, self.n_hot = None, 0
+        node_field = node_a
+        room = (LDS_TABLE_BYTES - 256 * int(lds_rel_rows)) // 256
+        whole_fits = 0 < int(n_gather_rows) <= room
+        if hot_cache and n_edges and node_b is None and not wide_ids and not whole_fits and room >= 16:
+            counts = torch.bincount(node_a, minlength=n_a)
+            k = int(min(HOT_MAX, room, int((counts > 0).sum())))
+            top = torch.topk(counts, k)
+            if k >= 16 and float(top.values.sum()) >= HOT_MIN_COVERAGE * n_edges and \
+                    8 + bits_rel + (n_a + k - 1).bit_length() <= 32:
+                self.n_hot = k
+                self.hot_nodes = top.indices.to(i32).contiguous()
+                slot = torch.full((n_a,), -1, dtype=torch.long, device=dev)
+                slot[top.indices] = torch.arange(k, device=dev)
+                node_slot = slot[node_a]
+                node_field = torch.where(node_slot >= 0, node_slot, node_a + k)
+                n_a = n_a + k
         if n_edges and chunk_rows <= 256 and 8 + bits_rel + max((n_a - 1).bit_length(), 1) <= 32 and not (
                 wide_ids and node_b is None):
             delta = row - row_begin[row]
-            word = delta | ((rel << 8) if bits_rel else 0) | (node_a << (8 + bits_rel))
+            word = delta | ((rel << 8) if bits_rel else 0) | (node_field << (8 + bits_rel))
             word = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(i32)
             # PACK_SLACK zero words after the last edge: the kernel always loads whole batches of 8 words
             self.packed = torch.cat([word, torch.zeros(PACK_SLACK, dtype=i32, device=dev)]).contiguous()
@@ -114,6 +139,8 @@ class Segments:
         s.piece_len = self.piece_len
         s.packed = self.packed.data_ptr() if self.packed is not None else None
         s.packed_src_shift = self.packed_src_shift
+        s.n_hot = self.n_hot
+        s.hot_nodes = self.hot_nodes.data_ptr() if self.hot_nodes is not None else None
 
     @property
     def pointer(self):
@@ -199,7 +226,7 @@ class RelCSR:
     """Coalesced relational adjacency of shape ``(n_dst, n_src, n_rel)`` plus its reduction plans."""
 
     def __init__(self, dst, src, rel, weight, n_dst, n_src, n_rel, chunk_edges=None, chunk_rows=CHUNK_ROWS,
-                 piece_len=None, balance=True, wide_ids=False):
+                 piece_len=None, balance=True, wide_ids=False, hot_cache=False):
         """``dst/src/rel``: int64 tensors [E] (any order, duplicates allowed); ``weight``: fp32 [E] or None (ones)."""
         dev = dst.device
         dst, src, rel = dst.long(), src.long(), rel.long()
@@ -212,7 +239,7 @@ class RelCSR:
             raise ValueError("adjacency too large for a 64-bit sort key")
         self.shape = (n_dst, n_src, n_rel)
         self._requested = (chunk_edges, piece_len)
-        self._opts = dict(chunk_rows=chunk_rows, balance=balance, wide_ids=wide_ids)
+        self._opts = dict(chunk_rows=chunk_rows, balance=balance, wide_ids=wide_ids, hot_cache=hot_cache)
         if weight is None:
             weight = torch.ones(dst.shape[0], dtype=torch.float32, device=dev)
         weight = weight.to(torch.float32)
@@ -276,7 +303,8 @@ class RelCSR:
         if self._fwd is None and getattr(self, "_base", None) is not None:
             self._fwd = self._base.fwd.reweighted(self.weight)
         if self._fwd is None:
-            self._fwd = Segments(self.dst, self.src, None, self.rel_id, self._w(), self.shape[0], **self._opts)
+            self._fwd = Segments(self.dst, self.src, None, self.rel_id, self._w(), self.shape[0],
+                                 lds_rel_rows=self.shape[2], n_gather_rows=self.shape[1], **self._opts)
         return self._fwd
 
     @property
@@ -290,7 +318,7 @@ class RelCSR:
             order = torch.sort(key, stable=True).indices
             self._by_src_order = order
             self._by_src = Segments(self.src[order], self.dst[order], None, self.rel_id[order], self._w(order), n_src,
-                                    **self._opts)
+                                    lds_rel_rows=n_rel, n_gather_rows=n_dst, **self._opts)
         return self._by_src
 
     @property
