@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--general", action="store_true")
     ap.add_argument("--backward", action="store_true")
+    ap.add_argument("--combine", action="store_true", help="time the fused layer epilogue (forward, or fwd+bwd with --backward)")
     args = ap.parse_args()
     import ultra_torchdrug_amd as U
     from ultra_torchdrug_amd import _lib, relcsr, functional as UF
@@ -38,7 +39,19 @@ def main():
     x = torch.randn(g.num_node, F, generator=gen).to(dev)
     grad = torch.randn(g.num_node, F, generator=gen).to(dev)
 
+    if args.combine:
+        lin, norm = torch.nn.Linear(128, 64).to(dev), torch.nn.LayerNorm(64).to(dev)
+        xi = x.view(g.num_node, args.batch, 64)
+        up = grad.view(g.num_node, args.batch, 64)
+        if args.backward:
+            xi = xi.clone().requires_grad_()
+
     def run():
+        if args.combine:
+            if args.backward:
+                out = UF.combine(xi, up, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, True)
+                return torch.autograd.grad(out, [xi, lin.weight], grad_outputs=up)
+            return UF.combine_forward(xi, up, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, True)
         if args.backward:
             return UF.rspmm_backward(csr, relation, x, None, grad, "add", "mul")
         return UF.rspmm_forward(csr, relation, x, "add", "mul")

@@ -654,6 +654,10 @@ __global__ __launch_bounds__(kCbWaves * 64, 2) void combine_kernel(const Combine
     const float bias0 = p.bias[i], bias1 = p.bias[i + 32];
     // LayerNorm role of this lane: row = lane >> 1, columns [32 * (lane & 1), +32)
     const int ln_row = lane >> 1, ln_half = lane & 1;
+    // gamma | beta in LDS behind the tiles (a global load per element inside the row loop costs more than the GEMM)
+    float *gb = cb_lds + kCbWaves * kCbTileFloats;
+    if (p.gamma != nullptr && threadIdx.x < 128) gb[threadIdx.x] = threadIdx.x < 64 ? p.gamma[threadIdx.x] : p.beta[threadIdx.x - 64];
+    __syncthreads();
 
     for (long long t = wave_global; t < n_tiles; t += wave_total) {
         const long long row0 = t * kCbRows;
@@ -718,9 +722,13 @@ __global__ __launch_bounds__(kCbWaves * 64, 2) void combine_kernel(const Combine
             const float var = (ln_half == 0 ? ss + sso : sso + ss) * (1.0f / 64.0f);
             const float inv = 1.0f / sqrtf(var + p.eps);
 #pragma unroll
-            for (int c = 0; c < 32; ++c) {
-                const int col = 32 * ln_half + c;
-                v[c] = ((v[c] - mean) * inv) * p.gamma[col] + p.beta[col];
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 gq = *reinterpret_cast<const f32x4 *>(gb + 32 * ln_half + 4 * q);
+                const f32x4 bq = *reinterpret_cast<const f32x4 *>(gb + 64 + 32 * ln_half + 4 * q);
+                v[4 * q + 0] = ((v[4 * q + 0] - mean) * inv) * gq.x + bq.x;
+                v[4 * q + 1] = ((v[4 * q + 1] - mean) * inv) * gq.y + bq.y;
+                v[4 * q + 2] = ((v[4 * q + 2] - mean) * inv) * gq.z + bq.z;
+                v[4 * q + 3] = ((v[4 * q + 3] - mean) * inv) * gq.w + bq.w;
             }
         }
         if (p.relu) {
@@ -1243,7 +1251,7 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
     long long blocks = (n_tiles + kCbWaves - 1) / kCbWaves;
     const long long resident = (long long)di->n_cu * 2;
     if (blocks > resident) blocks = resident;
-    const size_t lds = (size_t)kCbWaves * kCbTileFloats * sizeof(float);
+    const size_t lds = (size_t)(kCbWaves * kCbTileFloats + 128) * sizeof(float);
     static bool attr_set[16] = {false};
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel),
