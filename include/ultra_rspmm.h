@@ -201,6 +201,32 @@ int ultra_linear_forward_f32(const float *input, const float *weight, const floa
 int ultra_score_forward_f32(const float *hidden, const float *query, const float *w1, const float *b1, const float *w2,
                             const float *b2, float *out, int64_t n_node, int64_t batch, void *stream);
 
+
+/*
+ * Native plan builder (rocPRIM radix sort + scans), replaces sparse.coalesce() + coo2csr that torchdrug runs inside
+ * every generalized_rspmm call (/root/reference/ultra/layer.py:127,328 pass an un-coalesced adjacency).
+ *
+ * ultra_relcsr_coalesce: sort the (row, col, rel) triples, merge duplicates by summing their weights (weight may be
+ *   NULL = ones).  Outputs have capacity n_edges; *n_unique_host / *unit_weight_host (every merged weight == 1.0f)
+ *   are valid on return (the call synchronises the stream).  edge_of_input[i] = index of input edge i in the output.
+ * ultra_relcsr_plan: chunk schedule + packed words for ONE ordered plan (`row` non-decreasing).  Capacities:
+ *   chunks >= n_rows + n_edges / piece_len + 2 entries of 4 ints, long_rows >= n_edges / piece_len + 1 entries of
+ *   3 ints, packed n_edges + packed_slack ints (or NULL).  counts_host[4] = {n_chunks, n_long_rows, n_pieces,
+ *   packed_src_shift (0: none, 32: node ids stay in node_a)}.  is_relation_plan: rows are relations (no relation field).
+ * The *_temp_bytes functions give the scratch size each call needs.
+ */
+size_t ultra_relcsr_coalesce_temp_bytes(int64_t n_edges);
+int ultra_relcsr_coalesce(const int64_t *row, const int64_t *col, const int64_t *rel, const float *weight,
+                          int64_t n_edges, int64_t n_rows, int64_t n_cols, int64_t n_rel, int32_t *out_row,
+                          int32_t *out_col, int32_t *out_rel, float *out_weight, int64_t *edge_of_input,
+                          int64_t *n_unique_host, int *unit_weight_host, void *temp, size_t temp_bytes, void *stream);
+size_t ultra_relcsr_plan_temp_bytes(int64_t n_edges, int64_t n_rows, int64_t piece_len);
+int ultra_relcsr_plan(const int32_t *row, const int32_t *node_a, const int32_t *rel, int64_t n_edges, int64_t n_rows,
+                      int64_t n_node_a, int64_t n_rel, int is_relation_plan, int wide_ids, int balance,
+                      int64_t chunk_edges, int64_t chunk_rows, int64_t piece_len, int32_t *chunks,
+                      int64_t cap_chunks, int32_t *long_rows, int64_t cap_long, int32_t *packed,
+                      int64_t packed_slack, int64_t *counts_host, void *temp, size_t temp_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,10 @@ EXPORTS = (
     "ultra_combine_backward_f32",
     "ultra_linear_forward_f32",
     "ultra_score_forward_f32",
+    "ultra_relcsr_coalesce_temp_bytes",
+    "ultra_relcsr_coalesce",
+    "ultra_relcsr_plan_temp_bytes",
+    "ultra_relcsr_plan",
 )
 
 _lib = None
@@ -121,6 +125,16 @@ def load():
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.ultra_score_forward_f32.restype = i32
     lib.ultra_score_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    lib.ultra_relcsr_coalesce_temp_bytes.restype = sz
+    lib.ultra_relcsr_coalesce_temp_bytes.argtypes = [i64]
+    lib.ultra_relcsr_coalesce.restype = i32
+    lib.ultra_relcsr_coalesce.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp,
+                                          ctypes.POINTER(i64), ctypes.POINTER(i32), vp, sz, vp]
+    lib.ultra_relcsr_plan_temp_bytes.restype = sz
+    lib.ultra_relcsr_plan_temp_bytes.argtypes = [i64, i64, i64]
+    lib.ultra_relcsr_plan.restype = i32
+    lib.ultra_relcsr_plan.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, i64, i64, i64, vp, i64, vp, i64,
+                                      vp, i64, ctypes.POINTER(i64), vp, sz, vp]
     if lib.ultra_rspmm_abi_version() != ABI_VERSION:
         raise UltraLibraryError("ABI mismatch: library %d, binding %d" % (lib.ultra_rspmm_abi_version(), ABI_VERSION))
     _lib = lib

@@ -26,6 +26,9 @@
 
 #include "ultra_rspmm.h"
 
+// hipError_t of the last failing HIP call on this thread; shared with relcsr_build.hip
+thread_local int ultra_detail_last_hip_error = 0;
+
 namespace {
 
 constexpr int kTile = 64;            // columns per tile == wave width
@@ -764,7 +767,6 @@ __global__ __launch_bounds__(kCbWaves * 64, 2) void combine_kernel(const Combine
 
 // ------------------------------------------------------------------------------------------------ host side
 
-thread_local int g_last_hip_error = 0;
 // one-shot profiling events (ultra_rspmm_profile_next): bracket the next plan's segment kernel on its stream
 thread_local hipEvent_t g_prof_start = nullptr;
 thread_local hipEvent_t g_prof_stop = nullptr;
@@ -776,7 +778,7 @@ bool g_no_x_lds = false;
     do {                                                \
         hipError_t _e = (expr);                         \
         if (_e != hipSuccess) {                         \
-            g_last_hip_error = (int)_e;                 \
+            ultra_detail_last_hip_error = (int)_e;                 \
             (void)hipGetLastError();                    \
             return ULTRA_ERR_HIP;                       \
         }                                               \
@@ -1090,7 +1092,7 @@ const char *ultra_rspmm_status_string(int status) {
     }
 }
 
-int ultra_rspmm_last_hip_error(void) { return g_last_hip_error; }
+int ultra_rspmm_last_hip_error(void) { return ultra_detail_last_hip_error; }
 
 int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_host, size_t arch_len) {
     DeviceInfo *di = nullptr;

@@ -22,6 +22,7 @@ and added in piece order, which is the summation order ``oracle/rspmm_oracle.c``
 torch is used here for device memory and sorting only (plumbing).
 """
 import ctypes
+import os
 
 import torch
 
@@ -51,9 +52,12 @@ class Segments:
     """One reduction plan; owns the device tensors and the ``ultra_segments`` struct pointing at them."""
 
     def __init__(self, row, node_a, node_b, rel, weight, n_rows, chunk_edges=CHUNK_EDGES, chunk_rows=CHUNK_ROWS,
-                 piece_len=PIECE_LEN, balance=True, wide_ids=False, lds_rel_rows=0, n_gather_rows=0, hot_cache=False):
+                 piece_len=PIECE_LEN, balance=True, wide_ids=False, lds_rel_rows=0, n_gather_rows=0, hot_cache=False,
+                 n_node_a=None, n_rel_table=None, builder=None):
         """``wide_ids`` forces the big-graph word layout (node ids outside the packed word) even when they would fit
-        -- used by tests to exercise that kernel variant on small graphs."""
+        -- used by tests to exercise that kernel variant on small graphs.  ``n_node_a`` / ``n_rel_table``: declared
+        ranges of the id fields (bit widths of the packed word).  ``builder``: "native" (libultra_rspmm, rocPRIM; the
+        default for device tensors) or "torch" (the same construction in torch ops; CPU tensors, cross-check)."""
         n_edges = int(row.shape[0])
         if n_rows > _INT32_MAX or n_edges > _INT32_MAX:
             raise ValueError("graph too large for int32 indices: %d rows, %d edges" % (n_rows, n_edges))
@@ -67,16 +71,25 @@ class Segments:
         self.weight = None if weight is None else torch.cat(
             [weight.to(torch.float32), torch.ones(PACK_SLACK, dtype=torch.float32, device=dev)]).contiguous()
 
+        n_rel = int(n_rel_table) if n_rel_table is not None else (int(rel.max()) + 1 if n_edges else 1)
+        n_a = int(n_node_a) if n_node_a is not None else (int(node_a.max()) + 1 if n_edges else 1)
+        self.hot_nodes, self.n_hot = None, 0
+        self.packed, self.packed_src_shift = None, 0
+        if builder is None:
+            builder = os.environ.get("ULTRA_RELCSR_BUILDER") or ("native" if row.is_cuda else "torch")
+        self.builder = "torch" if (hot_cache or not row.is_cuda) else builder
+        if self.builder == "native":
+            self._build_native(n_a, n_rel, chunk_edges, chunk_rows, piece_len, balance, wide_ids)
+            self.struct = _lib.UltraSegments()
+            self._refresh_struct()
+            return
+
         deg = torch.bincount(row, minlength=n_rows) if n_edges else torch.zeros(n_rows, dtype=torch.long, device=dev)
         row_ptr = torch.zeros(n_rows + 1, dtype=torch.long, device=dev)
         torch.cumsum(deg, 0, out=row_ptr[1:])
-        self.row_ptr = row_ptr
         chunks, long_rows, n_pieces, row_begin = _schedule(row_ptr, deg, chunk_edges, chunk_rows, piece_len, balance)
         self.chunks = chunks.to(i32).contiguous()
         # packed edge words for the fast path: row delta | relation << 8 | node_a << src_shift   (ultra_rspmm.h)
-        self.packed, self.packed_src_shift = None, 0
-        n_rel = int(rel.max()) + 1 if n_edges else 1
-        n_a = int(node_a.max()) + 1 if n_edges else 1
         # d_relation plan (node_b given): the row IS the relation, no relation field; the word holds node_a only
         bits_rel = 0 if node_b is not None else max((n_rel - 1).bit_length(), 1)
         # hot-row cache (forward / d_input plans of KG-sized graphs): the most frequently gathered nodes, as many as fit
@@ -84,7 +97,6 @@ class Segments:
         # OFF by default: measured SLOWER on MI355X (S-fb15k237 forward 193 -> 250 us, S-wn18rr 122 -> 186 us): the
         # per-edge scalar branch breaks the 8-deep load batches and an LDS read is no cheaper than an L1-hit gather
         # in this instruction-bound loop; kept (tested, bit-identical) as a tuning switch.
-        self.hot_nodes, self.n_hot = None, 0
         node_field = node_a
         room = (LDS_TABLE_BYTES - 256 * int(lds_rel_rows)) // 256
         whole_fits = 0 < int(n_gather_rows) <= room
@@ -122,6 +134,34 @@ class Segments:
 
         self.struct = _lib.UltraSegments()
         self._refresh_struct()
+
+    def _build_native(self, n_a, n_rel, chunk_edges, chunk_rows, piece_len, balance, wide_ids):
+        """Chunk schedule + packed words through ``ultra_relcsr_plan`` (csrc/relcsr_build.hip)."""
+        lib = _lib.load()
+        dev, i32 = self.row.device, torch.int32
+        E, R = self.n_edges, self.n_rows
+        cap_chunks = R + E // piece_len + 2
+        cap_long = E // piece_len + 1
+        chunks = torch.empty(cap_chunks, 4, dtype=i32, device=dev)
+        long_rows = torch.empty(cap_long, 3, dtype=i32, device=dev)
+        packed = torch.empty(E + PACK_SLACK, dtype=i32, device=dev) if E else None
+        temp = torch.empty(int(lib.ultra_relcsr_plan_temp_bytes(E, R, piece_len)), dtype=torch.uint8, device=dev)
+        counts = (ctypes.c_int64 * 4)()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_relcsr_plan(
+                self.row.data_ptr(), self.node_a.data_ptr(), self.rel.data_ptr(), E, R, n_a, n_rel,
+                int(self.node_b is not None), int(bool(wide_ids)), int(bool(balance)), chunk_edges, chunk_rows, piece_len,
+                chunks.data_ptr(), cap_chunks, long_rows.data_ptr(), cap_long,
+                packed.data_ptr() if packed is not None else None, PACK_SLACK, counts, temp.data_ptr(), temp.numel(),
+                torch.cuda.current_stream().cuda_stream))
+        n_chunks, n_long, n_pieces, shift = (int(c) for c in counts)
+        self.chunks = chunks[:n_chunks].clone()
+        self.long_rows = long_rows[:n_long].clone()
+        self.n_pieces = n_pieces
+        if shift:
+            self.packed, self.packed_src_shift = packed, shift
+            if shift == 32:     # node ids are read from node_a in whole batches: same slack as the packed words
+                self.node_a = torch.cat([self.node_a, torch.zeros(PACK_SLACK, dtype=i32, device=dev)]).contiguous()
 
     def _refresh_struct(self):
         s = self.struct
@@ -226,7 +266,7 @@ class RelCSR:
     """Coalesced relational adjacency of shape ``(n_dst, n_src, n_rel)`` plus its reduction plans."""
 
     def __init__(self, dst, src, rel, weight, n_dst, n_src, n_rel, chunk_edges=None, chunk_rows=CHUNK_ROWS,
-                 piece_len=None, balance=True, wide_ids=False, hot_cache=False):
+                 piece_len=None, balance=True, wide_ids=False, hot_cache=False, builder=None):
         """``dst/src/rel``: int64 tensors [E] (any order, duplicates allowed); ``weight``: fp32 [E] or None (ones)."""
         dev = dst.device
         dst, src, rel = dst.long(), src.long(), rel.long()
@@ -239,15 +279,20 @@ class RelCSR:
             raise ValueError("adjacency too large for a 64-bit sort key")
         self.shape = (n_dst, n_src, n_rel)
         self._requested = (chunk_edges, piece_len)
-        self._opts = dict(chunk_rows=chunk_rows, balance=balance, wide_ids=wide_ids, hot_cache=hot_cache)
+        self._opts = dict(chunk_rows=chunk_rows, balance=balance, wide_ids=wide_ids, hot_cache=hot_cache,
+                          builder=builder)
         if weight is None:
             weight = torch.ones(dst.shape[0], dtype=torch.float32, device=dev)
         weight = weight.to(torch.float32)
 
         # coalesce: sort by (dst, src, rel), merge duplicate triples by summing their weights
-        key = (dst * n_src + src) * max(n_rel, 1) + rel
-        key, order = torch.sort(key, stable=True)
-        if key.numel():
+        if builder is None:
+            builder = os.environ.get("ULTRA_RELCSR_BUILDER") or ("native" if dst.is_cuda else "torch")
+        if builder == "native" and dst.is_cuda and dst.numel():
+            dst, src, rel, w_merged, self.edge_of_input, unit = self._coalesce_native(dst, src, rel, weight)
+        elif dst.numel():
+            key = (dst * n_src + src) * max(n_rel, 1) + rel
+            key, order = torch.sort(key, stable=True)
             uniq, inverse, count = torch.unique_consecutive(key, return_inverse=True, return_counts=True)
             first = torch.cumsum(count, 0) - count
             w_sorted = weight[order]
@@ -257,11 +302,12 @@ class RelCSR:
             # position of every ORIGINAL edge in the coalesced list (for d_weight of a sparse tensor that requires grad)
             self.edge_of_input = torch.empty_like(order)
             self.edge_of_input[order] = inverse
+            unit = bool((w_merged == 1).all().item())
         else:
-            w_merged = weight
+            w_merged, unit = weight, True
             self.edge_of_input = torch.zeros(0, dtype=torch.long, device=dev)
         self.dst, self.src, self.rel_id = dst, src, rel
-        self.unit_weight = bool((w_merged == 1).all().item()) if w_merged.numel() else True
+        self.unit_weight = unit
         self.weight = w_merged
         self.n_edges = int(dst.shape[0])
         # chunk / piece sizes: explicit, or chosen from the coalesced edge count; ONE pair for all three plans, and
@@ -271,6 +317,27 @@ class RelCSR:
         self.piece_len = int(self._requested[1] or (auto_piece if self._requested[0] is None else 4 * self.chunk_edges))
         self._opts.update(chunk_edges=self.chunk_edges, piece_len=self.piece_len)
         self._fwd = self._by_src = self._by_rel = None
+
+    def _coalesce_native(self, dst, src, rel, weight):
+        """``ultra_relcsr_coalesce`` (csrc/relcsr_build.hip): radix sort of the 64-bit triple key + duplicate merge."""
+        lib = _lib.load()
+        dev, n = dst.device, int(dst.shape[0])
+        n_dst, n_src, n_rel = self.shape
+        dst, src, rel, weight = dst.contiguous(), src.contiguous(), rel.contiguous(), weight.contiguous()
+        out_idx = torch.empty(3, n, dtype=torch.int32, device=dev)
+        out_w = torch.empty(n, dtype=torch.float32, device=dev)
+        edge_of_input = torch.empty(n, dtype=torch.long, device=dev)
+        temp = torch.empty(int(lib.ultra_relcsr_coalesce_temp_bytes(n)), dtype=torch.uint8, device=dev)
+        n_unique, unit = ctypes.c_int64(0), ctypes.c_int(1)
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_relcsr_coalesce(
+                dst.data_ptr(), src.data_ptr(), rel.data_ptr(), weight.data_ptr(), n, n_dst, n_src, n_rel,
+                out_idx[0].data_ptr(), out_idx[1].data_ptr(), out_idx[2].data_ptr(), out_w.data_ptr(),
+                edge_of_input.data_ptr(), ctypes.byref(n_unique), ctypes.byref(unit), temp.data_ptr(), temp.numel(),
+                torch.cuda.current_stream().cuda_stream))
+        m = int(n_unique.value)
+        ids = out_idx[:, :m].long()        # int64: the by_src / by_rel sort keys are products of these
+        return ids[0], ids[1], ids[2], out_w[:m].clone(), edge_of_input, bool(unit.value)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -304,7 +371,8 @@ class RelCSR:
             self._fwd = self._base.fwd.reweighted(self.weight)
         if self._fwd is None:
             self._fwd = Segments(self.dst, self.src, None, self.rel_id, self._w(), self.shape[0],
-                                 lds_rel_rows=self.shape[2], n_gather_rows=self.shape[1], **self._opts)
+                                 lds_rel_rows=self.shape[2], n_gather_rows=self.shape[1], n_node_a=self.shape[1],
+                                 n_rel_table=self.shape[2], **self._opts)
         return self._fwd
 
     @property
@@ -318,7 +386,8 @@ class RelCSR:
             order = torch.sort(key, stable=True).indices
             self._by_src_order = order
             self._by_src = Segments(self.src[order], self.dst[order], None, self.rel_id[order], self._w(order), n_src,
-                                    lds_rel_rows=n_rel, n_gather_rows=n_dst, **self._opts)
+                                    lds_rel_rows=n_rel, n_gather_rows=n_dst, n_node_a=n_dst, n_rel_table=n_rel,
+                                    **self._opts)
         return self._by_src
 
     @property
@@ -332,7 +401,7 @@ class RelCSR:
             order = torch.sort(key, stable=True).indices
             self._by_rel_order = order
             self._by_rel = Segments(self.rel_id[order], self.src[order], self.dst[order], self.rel_id[order],
-                                    self._w(order), n_rel, **self._opts)
+                                    self._w(order), n_rel, n_node_a=n_src, n_rel_table=n_rel, **self._opts)
         return self._by_rel
 
     def with_edge_weights(self, edge_weight):
