@@ -7,9 +7,11 @@ Workload (BASELINE.json metric: "edges aggregated/sec ... FB15k237 6L x 64d rspm
 synthetic KG of FB15k237's size (N=14 541, 272 115 triples, 237 relations => E=544 230, R=474 after inverse
 edges), seeded random-init Ultra weights (6 x 64d entity stack + 6 x 64d relation stack).
 One STEP = one evaluation batch of B=16 test triples through ``predict`` (/root/reference/ultra/task.py:228-263):
-relation-graph Bellman-Ford (6 rspmm) + tail pass + head pass over all N candidates (2 x 6 rspmm + epilogues +
-score MLP) = 18 rspmm calls, exactly the reference's unit of evaluation work.  Unit of work = one edge message =
-one edge x one batch element x 64 fp32 lanes; a step aggregates 12*E*B + 6*E_rel*B of them.  All inputs are
+relation-graph Bellman-Ford (6 rspmm) + tail pass + head pass over all N candidates (the reference: 2 x 6 rspmm +
+epilogues + score MLP = 18 rspmm calls; here the tail and head queries share ONE 2B-wide Bellman-Ford, 6 launches of
+twice the width, every score bit-identical: tests/test_model_gpu.py) -- exactly the reference's unit of evaluation
+work.  Unit of work = one edge message = one edge x one batch element x 64 fp32 lanes; a step aggregates
+12*E*B + 6*E_rel*B of them.  All inputs are
 resident in HBM before the timed region.  Multi-GPU: every rank holds the graph and evaluates its own query
 batch (query sharding, no data-path collective) => weak scaling.
 
@@ -198,6 +200,9 @@ def main():
         _ = g.relcsr.fwd                                      # plans built before the timed region
     B = args.batch
     F = B * 64
+    # predict() scores tails and heads in ONE Bellman-Ford over 2B queries (task.fuse_sides): 6 entity launches of
+    # width 2F per step instead of 12 of width F -- the same edge messages
+    Fk = 2 * F
     edges_per_step = (12 * E + 6 * E_rel) * B
 
     # each rank evaluates its own strided shard of the seeded test triples (DistributedSampler-style)
@@ -258,9 +263,9 @@ def main():
         state["on"] = False
         if graphed is not None:     # dominant kernel, eager, same stream / shapes / fused epilogue as inside the step
             gen = torch.Generator(device=dev).manual_seed(DEFAULT_SEED)
-            xk = torch.randn(n_node, F, device=dev, generator=gen)
-            rk = torch.randn(R2, F, device=dev, generator=gen)
-            bk = torch.randn(n_node, F, device=dev, generator=gen)
+            xk = torch.randn(n_node, Fk, device=dev, generator=gen)
+            rk = torch.randn(R2, Fk, device=dev, generator=gen)
+            bk = torch.randn(n_node, Fk, device=dev, generator=gen)
             for _ in range(4):
                 real_forward(und.relcsr, rk, xk, "add", "mul", bk)
             state["on"] = True
@@ -287,11 +292,13 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_fwd_fb15k237.json")
     if args.workload == "S-fb15k237" and args.batch == 16 and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        tj = json.load(open(tpath))
+        if tj.get("F") == Fk:
+            traffic = tj.get("hbm_bytes_per_launch")
 
     kernel_ms = events.elapsed_ms()
     k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-    algo = bytes_algo(E, n_node, R2, F)
+    algo = bytes_algo(E, n_node, R2, Fk)
 
     # ---------------- MRR (after the timed region): HIP path, and HIP vs CPU-oracle path on the same weights --------
     def mrr_of(t, queries):
@@ -360,16 +367,16 @@ def main():
             "edges_per_step": edges_per_step,
             "plan_build_ms": plan_build_ms,
             "eager_ms_per_step": eager_ms,
-            "rspmm_kernel_only": {"kernel": "packed_kernel<FWD,add,mul,unit_w> (entity graph)",
+            "rspmm_kernel_only": {"kernel": "quad_kernel<FWD,add,mul,unit_w> (entity graph, F = %d: tail and head queries of the batch in one launch)" % Fk,
                                   "launches_timed": len(kernel_ms), "avg_ms": k_avg_ms,
                                   "timed": "every launch of the timed region" if graphed is None else
                                            "24 eager launches of the same kernel/shapes right after the timed region "
                                            "(event records cannot be captured into the hipGraph with this HIP runtime)",
-                                  "edges_per_s": E * B / (k_avg_ms * 1e-3) if kernel_ms else None},
+                                  "edges_per_s": E * (Fk // 64) / (k_avg_ms * 1e-3) if kernel_ms else None},
             "roofline": {"bound": "hbm", "achieved": algo / (k_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "algorithmic bytes/launch = %d (SURVEY 8d); input (%.0f MB) is Infinity-Cache/L2 "
-                                 "resident at this size, so achieved may exceed HBM peak" % (algo, n_node * F * 4 / 1e6)},
+                                 "resident at this size, so achieved may exceed HBM peak" % (algo, n_node * Fk * 4 / 1e6)},
             "mrr_hip": mrr,
             "mrr_hip_after_finetune": mrr_tuned,
             "mrr_check": mrr_check,

@@ -161,3 +161,26 @@ def test_fused_score_head_equals_unfused_path():
             ref = l2(torch.relu(l1(feature))).squeeze(-1)
         assert torch.equal(fused, plain)
         torch.testing.assert_close(fused, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_fused_sides_predict_equals_two_model_calls():
+    """task.predict scores tails and heads in one 2B-query Bellman-Ford; the reference issues two B-query calls
+    (task.py:249-259).  Queries are independent columns: every score must be identical, on both paths."""
+    task, triples = _build((1200, 9000, 12))
+    rng = np.random.default_rng(11)
+    batch = torch.from_numpy(triples[rng.choice(len(triples), 16, replace=False)])
+    assert task.fuse_sides and task.full_batch_eval
+    with torch.no_grad(), oracle_rspmm(None):
+        fused_cpu = task.predict(batch)
+        task.fuse_sides = False
+        plain_cpu = task.predict(batch)
+        task.fuse_sides = True
+    assert torch.equal(fused_cpu, plain_cpu)
+    dev = torch.device("cuda:0")
+    task.to(dev)
+    with torch.no_grad():
+        fused = task.predict(batch.to(dev))
+        task.fuse_sides = False
+        plain = task.predict(batch.to(dev))
+    assert fused.shape == plain.shape == (16, 2, 1200)
+    assert torch.equal(fused, plain) and torch.equal(fused.cpu(), fused_cpu)

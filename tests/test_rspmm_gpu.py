@@ -259,7 +259,7 @@ def test_committed_golden_vectors(general):
 
 @pytest.mark.parametrize("case", ["skewed_hub", "small_weights"])
 def test_general_kernel_equals_packed_kernel(oracle, case):
-    """Both forward kernels implement one summation order: identical output."""
+    """All forward kernels implement one summation order: identical output."""
     import ultra_torchdrug_amd as U
     from ultra_torchdrug_amd import functional as UF
     kw, n, r, F = CASES[case]
@@ -270,15 +270,46 @@ def test_general_kernel_equals_packed_kernel(oracle, case):
     assert csr.fwd.packed is not None
     lib = U.require_library()
     outs = []
-    for general in (0, 1, 2):      # 0: packed (+ x staged in LDS when it fits), 1: general kernel, 2: packed, x from L2
+    # bit 0: general kernel; bit 1: gathered matrix from L2 even when it fits LDS; bit 2: one chunk per wave
+    # (packed_kernel) instead of four (quad_kernel).  0 = the default: quad (+ x staged in LDS when it fits)
+    for general in (0, 1, 2, 4, 6):
         lib.ultra_rspmm_force_general_path(general)
         try:
             outs.append([UF.rspmm_forward(csr, torch.from_numpy(relation).to(dev), torch.from_numpy(x).to(dev), s, m)
                          for s in SUMS for m in MULS])
         finally:
             lib.ultra_rspmm_force_general_path(0)
-    for a, b, c in zip(*outs):
-        assert torch.equal(a, b) and torch.equal(a, c)
+    for first, *others in zip(*outs):
+        for other in others:
+            assert torch.equal(first, other)
+
+
+@pytest.mark.parametrize("case", ["skewed_hub", "small_weights"])
+def test_backward_kernels_agree(oracle, case):
+    """d_input / d_relation of sum-aggregation: quad_kernel == packed_kernel == general kernel, bit for bit."""
+    import ultra_torchdrug_amd as U
+    from ultra_torchdrug_amd import functional as UF
+    kw, n, r, F = CASES[case]
+    g = random_graph(seed=78, n_node=n, n_rel=r, **kw)
+    relation, x = _inputs(7, n, r, F)
+    grad = np.random.default_rng(79).standard_normal((n, F)).astype(np.float32)
+    dev = _dev()
+    csr = _relcsr(g, n, n, r)
+    lib = U.require_library()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    outs = []
+    for flags in (0, 4, 1):
+        lib.ultra_rspmm_force_general_path(flags)
+        try:
+            outs.append([UF.rspmm_backward(csr, t(relation), t(x), None, t(grad), "add", m) for m in MULS])
+        finally:
+            lib.ultra_rspmm_force_general_path(0)
+    for first, *others in zip(*outs):
+        for other in others:
+            for a, b in zip(first, other):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("rows", [1, 31, 32, 33, 4096 + 17, 14541 * 16])

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--general", action="store_true")
     ap.add_argument("--backward", action="store_true")
+    ap.add_argument("--hot", action="store_true", help="plans with the LDS hot-row cache (kernel VAR 4)")
     ap.add_argument("--combine", action="store_true", help="time the fused layer epilogue (forward, or fwd+bwd with --backward)")
     args = ap.parse_args()
     import ultra_torchdrug_amd as U
@@ -31,7 +32,7 @@ def main():
     lib.ultra_rspmm_force_general_path(1 if args.general else 0)
     dev = torch.device("cuda:0")
     g = synthetic_kg(args.workload, device=dev).undirected(add_inverse=True)
-    opts = dict(piece_len=args.piece, chunk_edges=args.chunk)      # None: chosen from the edge count
+    opts = dict(piece_len=args.piece, chunk_edges=args.chunk, hot_cache=args.hot)      # None: chosen from the edge count
     csr = U.RelCSR.from_edge_list(g.edge_list, g.edge_weight, g.num_node, g.num_relation, **opts)
     F = args.batch * 64
     gen = torch.Generator(device="cpu").manual_seed(0)
@@ -70,6 +71,8 @@ def main():
     times = np.array(times)
     E = csr.n_edges
     algo = E * (4 * F + 12) + 4 * g.num_node * F + 4 * g.num_relation * F
+    if args.hot:
+        print("hot rows cached:", csr.fwd.n_hot)
     print("%s lib=%s %s B=%d E=%d chunks=%d pieces=%d: median %.1f us  min %.1f us  (%.2f TB/s algorithmic, %.2e edge-msgs/s)"
           % (args.workload, os.path.basename(_lib.LIB_PATH), "bwd" if args.backward else "fwd", args.batch, E,
              csr.fwd.chunks.shape[0], csr.fwd.n_pieces, np.median(times), times.min(), algo / np.median(times) / 1e6,

@@ -20,6 +20,7 @@
 //  * compiled with -ffp-contract=off: message = w * (rel (*|+) x) is rounded before it is accumulated,
 //    exactly as the oracle does.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdint>
 #include <cstring>
@@ -287,6 +288,8 @@ struct PParams {
     float *partial;
     long long F;
     uint32_t gather_bytes;
+    uint32_t meta_bytes;     // quad_kernel: bytes of `meta` (and of `weight`): (n_edges + slack) * 4
+    uint32_t meta2_bytes;    // quad_kernel: bytes of `meta2`: n_edges * 4
     uint32_t gather2_bytes;
     uint32_t relation_bytes;
     int n_gather_rows;
@@ -567,6 +570,8 @@ __global__ __launch_bounds__(256) void fixup_kernel(const FixParams p) {
     p.out[(long long)row * p.F + col] = acc;
 }
 
+#include "quad.inc"
+
 // d_weight[e] = sum_f (grad[dst,f] * dmask) * (relation[rel,f] MUL input[src,f]); one wave per edge.
 template <int SUM, int MUL, bool UNIT_W>
 __global__ __launch_bounds__(256) void weight_grad_kernel(const int32_t *row, const int32_t *src, const int32_t *rel,
@@ -773,6 +778,11 @@ thread_local hipEvent_t g_prof_stop = nullptr;
 // test/bench knob (ultra_rspmm_force_general_path): run the general kernel even where the packed one applies
 bool g_force_general = false;
 bool g_no_x_lds = false;
+bool g_no_quad = false;
+#ifndef ULTRA_QUAD_U
+#define ULTRA_QUAD_U 8
+#endif
+constexpr int kQuadU = ULTRA_QUAD_U;   // edges per group in flight (quad_kernel)
 
 #define HIP_TRY(expr)                                   \
     do {                                                \
@@ -929,6 +939,41 @@ int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, int var
     return ULTRA_ERR_BAD_OP;
 }
 
+template <int KIND, int SUM, int MUL>
+int launch_quad_w(const PParams &p, bool unit_w, bool x_lds, int grid, size_t lds, hipStream_t stream) {
+    if constexpr (KIND != KIND_DREL) {
+        if (x_lds) {
+            if (unit_w) return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, true, kQuadU>, p, grid, lds, stream);
+            return launch_with_lds(quad_kernel<KIND, SUM, MUL, false, true, kQuadU>, p, grid, lds, stream);
+        }
+    }
+    if (unit_w) return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, false, kQuadU>, p, grid, lds, stream);
+    return launch_with_lds(quad_kernel<KIND, SUM, MUL, false, false, kQuadU>, p, grid, lds, stream);
+}
+
+template <int KIND>
+int launch_quad(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_lds, int grid, size_t lds,
+                hipStream_t stream) {
+    if constexpr (KIND == KIND_FWD) {
+#define ULTRA_QCASE(S, M) \
+    if (sum_op == S && mul_op == M) return launch_quad_w<KIND_FWD, S, M>(p, unit_w, x_lds, grid, lds, stream);
+        ULTRA_QCASE(ULTRA_SUM_ADD, ULTRA_MUL_MUL)
+        ULTRA_QCASE(ULTRA_SUM_ADD, ULTRA_MUL_ADD)
+        ULTRA_QCASE(ULTRA_SUM_MIN, ULTRA_MUL_MUL)
+        ULTRA_QCASE(ULTRA_SUM_MIN, ULTRA_MUL_ADD)
+        ULTRA_QCASE(ULTRA_SUM_MAX, ULTRA_MUL_MUL)
+        ULTRA_QCASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
+#undef ULTRA_QCASE
+    } else if constexpr (KIND == KIND_DX) {
+        if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream);
+        return launch_quad_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, x_lds, grid, lds, stream);
+    } else {
+        if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, false, grid, kLdsHeader, stream);
+        return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, false, grid, kLdsHeader, stream);
+    }
+    return ULTRA_ERR_BAD_OP;
+}
+
 // Runs one plan: segment_kernel over the chunk schedule, then fixup_kernel over the split rows.
 template <int KIND>
 int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t gather2_rows, int64_t n_rel, int64_t F,
@@ -1042,7 +1087,17 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
                 lds_bytes += lds_x_bytes;
             }
             q.n_gather_rows = (int)gather_rows;
-            rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var, grid, kLdsHeader + lds_bytes, stream);
+            // four chunks per wave, four columns per lane (quad.inc): needs 16-byte rows and pointers
+            auto aligned16 = [](const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; };
+            const unsigned long long meta_bytes = ((unsigned long long)seg->n_edges + 16ull) * 4ull;   // PACK_SLACK words follow
+            q.meta_bytes = (uint32_t)(meta_bytes < 0xffff0000ull ? meta_bytes : 0);
+            q.meta2_bytes = (uint32_t)((unsigned long long)seg->n_edges * 4ull);
+            const bool quad = !g_no_quad && (var == 0 || var == 1) && (F % 4) == 0 &&
+                              q.meta_bytes != 0 && (unsigned long long)F * 4ull < (1ull << 24) &&
+                              (KIND != KIND_DREL || gather2_rows < (1ll << 24)) && aligned16(gather) && aligned16(p.grad) &&
+                              aligned16(p.out) && aligned16(p.add_rows) && aligned16(p.partial);
+            if (quad) rc = launch_quad<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var == 1, grid, kLdsHeader + lds_bytes, stream);
+            if (!quad) rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var, grid, kLdsHeader + lds_bytes, stream);
             if (rc) return rc;
         }
     }
@@ -1110,6 +1165,7 @@ int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_ho
 int ultra_rspmm_force_general_path(int on) {
     g_force_general = (on & 1) != 0;      // bit 0: general kernel instead of the packed one
     g_no_x_lds = (on & 2) != 0;           // bit 1: packed kernel without staging the gathered matrix in LDS
+    g_no_quad = (on & 4) != 0;            // bit 2: one chunk per wave (packed_kernel) instead of four (quad_kernel)
     return ULTRA_OK;
 }
 

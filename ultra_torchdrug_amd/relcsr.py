@@ -31,13 +31,16 @@ from . import _lib
 CHUNK_ROWS = 64      # at most this many rows per chunk (bounds the work of runs of empty rows)
 
 
-def auto_sizes(n_edges):
+def auto_sizes(n_edges, wide=False):
     """(chunk_edges, piece_len) for a graph with ``n_edges`` coalesced edges.  Bigger chunks mean fewer pieces, less
-    fix-up traffic and longer runs of the branch-free batch path, but a wave needs several chunks per column tile to
-    stay busy (512 waves share a tile on an MI355X): measured best on S-codexs (66 k edges) 32 / 128, on S-wn18rr
-    (174 k), S-fb15k237 (544 k) and S-codexm 128 / 512 (tools/kbench.py --chunk --piece)."""
-    chunk = 128 if n_edges >= 150_000 else (64 if n_edges >= 100_000 else 32)
-    return chunk, 4 * chunk
+    fix-up traffic and longer runs of the branch-free batch path, but every 16-lane group of the quad kernel (four
+    chunks per wave, 2 048 groups share a column tile on an MI355X) needs a few chunks to stay busy.  Measured best
+    (tools/kbench.py --chunk --piece, forward / backward): S-codexs (66 k edges) and S-wn18rr (174 k) 32 / 128,
+    S-fb15k237 (544 k) 32 / 256.  ``wide``: node ids do not fit the packed word (one chunk per wave, kernel
+    variants 2 / 3): 128 / 512."""
+    if wide:
+        return 128, 512
+    return (32, 256) if n_edges >= 300_000 else (32, 128)
 
 
 CHUNK_EDGES, PIECE_LEN = auto_sizes(0)    # the sizes small graphs get (kept as names for explicit callers / tests)
@@ -312,7 +315,8 @@ class RelCSR:
         self.n_edges = int(dst.shape[0])
         # chunk / piece sizes: explicit, or chosen from the coalesced edge count; ONE pair for all three plans, and
         # `piece_len` is the summation-order parameter the oracle needs (oracle `piece`)
-        auto_chunk, auto_piece = auto_sizes(self.n_edges)
+        wide = wide_ids or 8 + max((n_rel - 1).bit_length(), 1) + max((max(n_dst, n_src) - 1).bit_length(), 1) > 32
+        auto_chunk, auto_piece = auto_sizes(self.n_edges, wide)
         self.chunk_edges = int(self._requested[0] or auto_chunk)
         self.piece_len = int(self._requested[1] or (auto_piece if self._requested[0] is None else 4 * self.chunk_edges))
         self._opts.update(chunk_edges=self.chunk_edges, piece_len=self.piece_len)

@@ -53,6 +53,10 @@ class KnowledgeGraphCompletion(nn.Module):
         self.sample_weight = sample_weight
         self.metric_per_rel = metric_per_rel
         self.full_batch_eval = full_batch_eval
+        # full-batch evaluation scores tails and heads in ONE Bellman-Ford over 2B queries instead of two over B
+        # (task.py:249-259 issues two model calls).  Queries are independent columns of every kernel on the path, so
+        # every score is bit-identical to the two-call form (tests/test_model_gpu.py); False = the literal two calls.
+        self.fuse_sides = True
         self.contexts = {}
         self.split = None
 
@@ -167,6 +171,16 @@ class KnowledgeGraphCompletion(nn.Module):
         pos_h_index, pos_t_index, pos_r_index = batch.t()
         batch_size = len(batch)
         rel_inputs = self.relation_representations(pos_r_index, all_loss, metric)
+
+        if all_loss is None and self.full_batch_eval and self.fuse_sides:         # evaluation, both sides at once
+            all_row = torch.arange(self.num_entity, device=batch.device).unsqueeze(0).expand(batch_size, -1)
+            pos_h, pos_t = (x.unsqueeze(-1).expand(-1, self.num_entity) for x in (pos_h_index, pos_t_index))
+            h_index = torch.cat([pos_h, all_row])           # rows B..2B-1 are head-corrupted: the model flips them
+            t_index = torch.cat([all_row, pos_t])           # to tail form with r + R (model.py:76-83)
+            r_index = pos_r_index.repeat(2).unsqueeze(-1).expand(-1, self.num_entity)
+            pred = self.model(self.fact_graph, [torch.cat([r, r]) for r in rel_inputs], h_index, t_index, r_index,
+                              all_entities=True)
+            return pred.view(2, batch_size, self.num_entity).transpose(0, 1).contiguous()    # (B, 2, N)
 
         if all_loss is None:                                                     # evaluation: all entities
             all_index = torch.arange(self.num_entity, device=batch.device)
