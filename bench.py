@@ -219,11 +219,11 @@ def main():
     real_forward = UF.rspmm_forward
     state = {"on": False}
 
-    def timed_forward(csr, relation, input, sum="add", mul="mul", add_rows=None):
+    def timed_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, boundary=None):
         if state["on"] and csr is und.relcsr:
             a, b = events.new_pair()
             lib.ultra_rspmm_profile_next(a, b)
-        return real_forward(csr, relation, input, sum, mul, add_rows)
+        return real_forward(csr, relation, input, sum, mul, add_rows, boundary)
 
     UF.rspmm_forward = timed_forward
 
@@ -265,12 +265,13 @@ def main():
             gen = torch.Generator(device=dev).manual_seed(DEFAULT_SEED)
             xk = torch.randn(n_node, Fk, device=dev, generator=gen)
             rk = torch.randn(R2, Fk, device=dev, generator=gen)
-            bk = torch.randn(n_node, Fk, device=dev, generator=gen)
+            bk = (torch.randint(0, n_node, (Fk // 64,), device=dev, generator=gen).to(torch.int32),
+                  torch.randn(Fk // 64, 64, device=dev, generator=gen))            # the layer's sparse boundary
             for _ in range(4):
-                real_forward(und.relcsr, rk, xk, "add", "mul", bk)
+                real_forward(und.relcsr, rk, xk, "add", "mul", None, bk)
             state["on"] = True
             for _ in range(24):
-                timed_forward(und.relcsr, rk, xk, "add", "mul", bk)
+                timed_forward(und.relcsr, rk, xk, "add", "mul", None, bk)
             state["on"] = False
             torch.cuda.synchronize()
             # un-captured step time, for reference

@@ -123,6 +123,18 @@ int ultra_rspmm_forward_f32(const ultra_segments *fwd_host, const float *relatio
                             const float *add_rows, float *out, void *workspace, size_t workspace_bytes,
                             int64_t n_src, int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream);
 
+/* Forward with the Bellman-Ford boundary in its sparse form (same kernels, no dense [n_rows, F] read per layer).
+ * The reference builds `boundary = zeros(N, B, D); boundary.scatter_add_(0, h_index, query)` (ultra/model.py:106-107,
+ * ultra/rel_model.py:114-115) and applies `update + boundary` / `max(update, boundary)` after every rspmm
+ * (ultra/layer.py:156,162,358,364).  Here: column c belongs to query block c / block; row boundary_node[c / block]
+ * holds boundary_value[c] in that column and every other element of the boundary is 0.
+ *   boundary_node  : int32 [F / block]     boundary_value : fp32 [F]     block : columns per query (64), F % block == 0
+ * Result identical to ultra_rspmm_forward_f32 with the dense tensor as add_rows. */
+int ultra_rspmm_forward_boundary_f32(const ultra_segments *fwd, const float *relation, const float *input,
+                                     const int32_t *boundary_node, const float *boundary_value, int64_t block, float *out,
+                                     void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_rel, int64_t F,
+                                     int sum_op, int mul_op, void *stream);
+
 /*
  * Gradients of the call above w.r.t. input and relation
  * replaces rspmm_{sum}_{mul}_backward_cuda(sparse, relation, input, output, output_grad).

@@ -167,6 +167,38 @@ def test_fused_boundary_epilogue(oracle):
         assert torch.equal(fused, want)
 
 
+@pytest.mark.parametrize("flags", [0, 4, 1])
+def test_sparse_boundary_equals_dense_boundary(flags):
+    """ultra_rspmm_forward_boundary_f32: the Bellman-Ford boundary as (node per query, value per query) instead of the
+    dense scatter_add_ result (model.py:106-107) -- identical output in every kernel (quad / packed / general),
+    including split rows (node 2 is a hub: fix-up path), an isolated boundary node and a repeated node."""
+    import ultra_torchdrug_amd as U
+    from ultra_torchdrug_amd import functional as UF
+    n, r, B, D = 300, 9, 5, 64
+    g = random_graph(seed=11, n_node=n, n_edge=9000, n_rel=r, skew=True, hub_row=2, hub_edges=1000, isolated=20)
+    relation, x = _inputs(4, n, r, B * D)
+    dev = _dev()
+    csr = _relcsr(g, n, n, r)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    node = torch.tensor([2, 7, 299, 7, 150], dtype=torch.int64, device=dev)          # hub, twice 7, isolated 299
+    value = torch.randn(B, D, generator=torch.Generator().manual_seed(3)).to(dev)
+    dense = torch.zeros(n, B, D, device=dev)
+    dense.scatter_add_(0, node.view(1, B, 1).expand(1, B, D), value.unsqueeze(0))
+    lib = U.require_library()
+    lib.ultra_rspmm_force_general_path(flags)
+    try:
+        for sum in SUMS:
+            want = UF.rspmm_forward(csr, t(relation), t(x), sum, "mul", add_rows=dense.flatten(1))
+            got = UF.rspmm_forward(csr, t(relation), t(x), sum, "mul", boundary=(node.to(torch.int32), value))
+            assert torch.equal(got, want)
+    finally:
+        lib.ultra_rspmm_force_general_path(0)
+    with pytest.raises(RuntimeError):
+        UF.rspmm_forward(csr, t(relation), t(x), "add", "mul", boundary=(node, value))            # int64 nodes
+    with pytest.raises(RuntimeError):
+        UF.rspmm_forward(csr, t(relation), t(x), "add", "mul", boundary=(node.to(torch.int32), value[:, :32]))
+
+
 def test_sparse_tensor_entry_and_errors():
     """Same call shape as the reference (layer.py:357): positional (adjacency, relation_input, input)."""
     from ultra_torchdrug_amd import functional as UF

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--general", action="store_true")
     ap.add_argument("--backward", action="store_true")
+    ap.add_argument("--boundary", action="store_true", help="forward with the fused `+ boundary` epilogue (add_rows), as inside a layer")
     ap.add_argument("--hot", action="store_true", help="plans with the LDS hot-row cache (kernel VAR 4)")
     ap.add_argument("--combine", action="store_true", help="time the fused layer epilogue (forward, or fwd+bwd with --backward)")
     args = ap.parse_args()
@@ -40,6 +41,8 @@ def main():
     x = torch.randn(g.num_node, F, generator=gen).to(dev)
     grad = torch.randn(g.num_node, F, generator=gen).to(dev)
 
+    bsparse = (torch.randint(0, g.num_node, (args.batch,), generator=gen).to(dev).to(torch.int32),
+               torch.randn(args.batch, 64, generator=gen).to(dev))
     if args.combine:
         lin, norm = torch.nn.Linear(128, 64).to(dev), torch.nn.LayerNorm(64).to(dev)
         xi = x.view(g.num_node, args.batch, 64)
@@ -55,6 +58,8 @@ def main():
             return UF.combine_forward(xi, up, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, True)
         if args.backward:
             return UF.rspmm_backward(csr, relation, x, None, grad, "add", "mul")
+        if args.boundary:     # the layer's fused `+ boundary` epilogue, sparse form
+            return UF.rspmm_forward(csr, relation, x, "add", "mul", boundary=bsparse)
         return UF.rspmm_forward(csr, relation, x, "add", "mul")
 
     for _ in range(5):

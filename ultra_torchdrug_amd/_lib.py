@@ -50,6 +50,7 @@ EXPORTS = (
     "ultra_rspmm_force_general_path",
     "ultra_rspmm_workspace_bytes",
     "ultra_rspmm_forward_f32",
+    "ultra_rspmm_forward_boundary_f32",
     "ultra_rspmm_backward_f32",
     "ultra_rspmm_backward_weight_f32",
     "ultra_combine_forward_f32",
@@ -111,6 +112,8 @@ def load():
     lib.ultra_rspmm_workspace_bytes.argtypes = [seg, i64]
     lib.ultra_rspmm_forward_f32.restype = i32
     lib.ultra_rspmm_forward_f32.argtypes = [seg, vp, vp, vp, vp, vp, sz, i64, i64, i64, i32, i32, vp]
+    lib.ultra_rspmm_forward_boundary_f32.restype = i32
+    lib.ultra_rspmm_forward_boundary_f32.argtypes = [seg, vp, vp, vp, vp, i64, vp, vp, sz, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_f32.restype = i32
     lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_weight_f32.restype = i32

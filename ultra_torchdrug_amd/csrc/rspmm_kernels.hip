@@ -58,6 +58,9 @@ struct KParams {
     const float *output;     // [n_dst, F]   (min/max backward only)
     const float *grad;       // [n_dst, F]   (backward only)
     const float *add_rows;   // [n_rows, F]  (forward only, optional fused epilogue)
+    const int32_t *bnode;    // forward only: sparse form of add_rows -- row bnode[c / bdim] holds bvec[c] in column c,
+    const float *bvec;       //   every other element is 0 (the Bellman-Ford boundary: ultra/model.py:106-107)
+    int bdim;
     float *out;              // [n_rows, F]
     float *partial;          // [n_pieces, F]
     long long F;
@@ -73,6 +76,9 @@ struct FixParams {
     const int32_t *long_rows;   // [n_long][3]
     const float *partial;
     const float *add_rows;
+    const int32_t *bnode;
+    const float *bvec;
+    int bdim;
     float *out;
     long long F;
     int n_long;
@@ -132,6 +138,7 @@ struct ChunkWalker {
         if (active) {
             if constexpr (KIND == KIND_FWD) {
                 if (p.add_rows != nullptr) v = reduce<RED>(v, p.add_rows[(long long)r * F + col]);
+                else if (p.bnode != nullptr) v = reduce<RED>(v, (r == p.bnode[col / p.bdim]) ? p.bvec[col] : 0.0f);
             }
             p.out[(long long)r * F + col] = v;
         }
@@ -284,12 +291,16 @@ struct PParams {
     const float *gather;     // forward: input [n_src, F]; d_input: output_grad [n_dst, F]; d_relation: input
     const float *gather2;    // d_relation: output_grad [n_dst, F]
     const float *add_rows;
+    const int32_t *bnode;    // sparse form of add_rows (see KParams)
+    const float *bvec;
+    int bdim;
     float *out;
     float *partial;
     long long F;
     uint32_t gather_bytes;
     uint32_t meta_bytes;     // quad_kernel: bytes of `meta` (and of `weight`): (n_edges + slack) * 4
     uint32_t meta2_bytes;    // quad_kernel: bytes of `meta2`: n_edges * 4
+    uint32_t out_bytes;      // quad_kernel: bytes of `out` (and of `add_rows`): n_rows * F * 4
     uint32_t gather2_bytes;
     uint32_t relation_bytes;
     int n_gather_rows;
@@ -395,10 +406,17 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
             }
         };
 
+        int b_node = -1;          // sparse boundary of this lane's column
+        float b_val = 0.0f;
+        if (KIND == KIND_FWD && p.bnode != nullptr && active) {
+            b_node = p.bnode[col / p.bdim];
+            b_val = p.bvec[col];
+        }
         auto store_row = [&](int r, float v) {
             if (active) {
                 if constexpr (KIND == KIND_FWD) {
                     if (p.add_rows != nullptr) v = reduce<RED>(v, p.add_rows[(long long)r * F + col]);
+                    else if (p.bnode != nullptr) v = reduce<RED>(v, (r == b_node) ? b_val : 0.0f);
                 }
                 p.out[(long long)r * F + col] = v;
             }
@@ -567,6 +585,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(const FixParams p) {
             if (k0 + u < n) acc = reduce<RED>(acc, v[u]);
     }
     if (p.add_rows != nullptr) acc = reduce<RED>(acc, p.add_rows[(long long)row * p.F + col]);
+    else if (p.bnode != nullptr) acc = reduce<RED>(acc, (row == p.bnode[col / p.bdim]) ? p.bvec[col] : 0.0f);
     p.out[(long long)row * p.F + col] = acc;
 }
 
@@ -1050,6 +1069,9 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
             q.gather = gather;
             q.gather2 = p.grad;
             q.add_rows = p.add_rows;
+            q.bnode = p.bnode;
+            q.bvec = p.bvec;
+            q.bdim = p.bdim;
             q.out = p.out;
             q.partial = p.partial;
             q.F = F;
@@ -1092,10 +1114,13 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
             const unsigned long long meta_bytes = ((unsigned long long)seg->n_edges + 16ull) * 4ull;   // PACK_SLACK words follow
             q.meta_bytes = (uint32_t)(meta_bytes < 0xffff0000ull ? meta_bytes : 0);
             q.meta2_bytes = (uint32_t)((unsigned long long)seg->n_edges * 4ull);
-            const bool quad = !g_no_quad && (var == 0 || var == 1) && (F % 4) == 0 &&
+            const unsigned long long out_bytes = (unsigned long long)seg->n_rows * (unsigned long long)F * 4ull;
+            q.out_bytes = (uint32_t)(out_bytes < 0xffff0000ull ? out_bytes : 0);
+            const bool quad = !g_no_quad && (var == 0 || var == 1) && (F % 4) == 0 && q.out_bytes != 0 &&
                               q.meta_bytes != 0 && (unsigned long long)F * 4ull < (1ull << 24) &&
                               (KIND != KIND_DREL || gather2_rows < (1ll << 24)) && aligned16(gather) && aligned16(p.grad) &&
-                              aligned16(p.out) && aligned16(p.add_rows) && aligned16(p.partial);
+                              aligned16(p.out) && aligned16(p.add_rows) && aligned16(p.partial) && aligned16(p.bvec) &&
+                              (p.bnode == nullptr || p.bdim % 4 == 0);
             if (quad) rc = launch_quad<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var == 1, grid, kLdsHeader + lds_bytes, stream);
             if (!quad) rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var, grid, kLdsHeader + lds_bytes, stream);
             if (rc) return rc;
@@ -1113,6 +1138,9 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
         fp.long_rows = seg->long_rows;
         fp.partial = p.partial;
         fp.add_rows = p.add_rows;
+        fp.bnode = p.bnode;
+        fp.bvec = p.bvec;
+        fp.bdim = p.bdim;
         fp.out = p.out;
         fp.F = F;
         fp.n_long = (int)seg->n_long_rows;
@@ -1210,6 +1238,25 @@ int ultra_rspmm_forward_f32(const ultra_segments *fwd, const float *relation, co
     p.relation = relation;
     p.input = input;
     p.add_rows = add_rows;
+    p.out = out;
+    return run_plan<KIND_FWD>(fwd, p, n_src, 0, n_rel, F, sum_op, mul_op, true, workspace, workspace_bytes,
+                              static_cast<hipStream_t>(stream));
+}
+
+int ultra_rspmm_forward_boundary_f32(const ultra_segments *fwd, const float *relation, const float *input,
+                                     const int32_t *boundary_node, const float *boundary_value, int64_t block, float *out,
+                                     void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_rel, int64_t F,
+                                     int sum_op, int mul_op, void *stream) {
+    if (fwd == nullptr || boundary_node == nullptr || boundary_value == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (fwd->n_rows > 0 && out == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (fwd->n_edges > 0 && (relation == nullptr || input == nullptr)) return ULTRA_ERR_NULL_POINTER;
+    if (block <= 0 || block > 0x7fffffffLL || F <= 0 || F % block != 0) return ULTRA_ERR_BAD_SHAPE;
+    KParams p{};
+    p.relation = relation;
+    p.input = input;
+    p.bnode = boundary_node;
+    p.bvec = boundary_value;
+    p.bdim = (int)block;
     p.out = out;
     return run_plan<KIND_FWD>(fwd, p, n_src, 0, n_rel, F, sum_op, mul_op, true, workspace, workspace_bytes,
                               static_cast<hipStream_t>(stream));

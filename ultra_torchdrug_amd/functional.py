@@ -84,8 +84,11 @@ def _workspace(seg, F, device):
     return ws, n * 4
 
 
-def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None):
-    """Forward only, no autograd.  ``add_rows`` fuses the boundary epilogue of ``layer.py:156,162,358,364``."""
+def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, boundary=None):
+    """Forward only, no autograd.  ``add_rows`` fuses the boundary epilogue of ``layer.py:156,162,358,364``;
+    ``boundary = (node, value)`` is the same epilogue with the boundary in its sparse form: ``node`` int32 ``(B,)``,
+    ``value`` fp32 ``(B, D)`` with ``B * D == F`` -- row ``node[b]`` of query block ``b`` holds ``value[b]``, all else 0
+    (what ``scatter_add_`` builds in ``model.py:106-107``)."""
     sum_op, mul_op = _ops(sum, mul)
     _check_dense(csr, relation, input)
     relation, input = relation.contiguous(), input.contiguous()
@@ -95,11 +98,27 @@ def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None):
         add_rows = add_rows.contiguous()
         if add_rows.shape != out.shape or add_rows.dtype != torch.float32 or add_rows.device != out.device:
             raise RuntimeError("add_rows must be fp32 %s on %s" % (tuple(out.shape), out.device))
+    if boundary is not None:
+        if add_rows is not None:
+            raise RuntimeError("give the boundary either dense (add_rows) or sparse (boundary), not both")
+        b_node, b_value = boundary
+        b_value = b_value.contiguous()
+        if (b_node.dtype != torch.int32 or b_value.dtype != torch.float32 or b_node.dim() != 1 or b_value.dim() != 2
+                or b_value.shape[0] != b_node.shape[0] or b_value.numel() != F or b_node.device != out.device
+                or b_value.device != out.device or not b_node.is_contiguous()):
+            raise RuntimeError("boundary must be (int32 (B,), fp32 (B, D)) with B * D == %d on %s" % (F, out.device))
     if out.numel() == 0:
         return out
     lib = _lib.load()
     seg = csr.fwd
     ws, ws_bytes = _workspace(seg, F, input.device)
+    if boundary is not None:
+        with torch.cuda.device(input.device):
+            _lib.check(lib.ultra_rspmm_forward_boundary_f32(
+                seg.pointer, relation.data_ptr(), input.data_ptr(), b_node.data_ptr(), b_value.data_ptr(),
+                b_value.shape[1], out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, csr.shape[1],
+                csr.shape[2], F, sum_op, mul_op, _stream()))
+        return out
     with torch.cuda.device(input.device):
         _lib.check(lib.ultra_rspmm_forward_f32(
             seg.pointer, relation.data_ptr(), input.data_ptr(), add_rows.data_ptr() if add_rows is not None else None,

@@ -186,9 +186,12 @@ class _RelationalConvBase(nn.Module):
         # inference: `update + boundary` / `max(update, boundary)` ride along in the rspmm kernel (bit-identical)
         fuse_bound = (bound and input.is_cuda and hasattr(functional, "rspmm_forward")
                       and self._no_grad(input, relation_input, boundary))
+        # the boundary in its sparse form (node per query, value per query), when the caller attached it
+        sparse_bound = getattr(graph, "boundary_sparse", None) if fuse_bound else None
+        bound_args = dict(add_rows=boundary) if sparse_bound is None else dict(boundary=sparse_bound)
         if kind in ("sum", "mean"):
             if fuse_bound:
-                update = functional.rspmm_forward(adjacency, relation_input, input, "add", mul, add_rows=boundary)
+                update = functional.rspmm_forward(adjacency, relation_input, input, "add", mul, **bound_args)
             elif bound and input.is_cuda and hasattr(functional, "rspmm_sum_plus"):
                 update = functional.rspmm_sum_plus(adjacency, relation_input, input, boundary, mul=mul)   # training
             else:
@@ -199,7 +202,7 @@ class _RelationalConvBase(nn.Module):
                 update = update / degree_out
         elif kind == "max":
             if fuse_bound:
-                update = functional.rspmm_forward(adjacency, relation_input, input, "max", mul, add_rows=boundary)
+                update = functional.rspmm_forward(adjacency, relation_input, input, "max", mul, **bound_args)
             else:
                 update = rspmm(adjacency, relation_input, input, sum="max", mul=mul)
                 if bound:

@@ -107,6 +107,9 @@ class TransferNBFNet(nn.Module):
         boundary.scatter_add_(0, index.unsqueeze(0), query.unsqueeze(0))
         graph.query = query
         graph.boundary = boundary
+        # the same boundary in sparse form: row h_index[b] of query block b holds query[b] (inference kernels read
+        # this instead of the dense tensor in every layer's epilogue)
+        graph.boundary_sparse = (h_index.to(torch.int32), query)
 
         hiddens, step_graphs = [], []
         layer_input = boundary

@@ -86,6 +86,7 @@ class CustomNBFNet(nn.Module):
         boundary[h_index] = 1.0
         graph.query = query.unsqueeze(0)
         graph.boundary = boundary.unsqueeze(1)
+        graph.boundary_sparse = None
         return {"node_feature": self._run_layers(graph, boundary.unsqueeze(1)).squeeze(1)}
 
     def forward(self, graph, h_index, t_index=None, r_index=None, all_loss=None, metric=None):
@@ -115,6 +116,7 @@ class CustomNBFNetFull(CustomNBFNet):
         boundary.scatter_add_(0, index.unsqueeze(0), query.unsqueeze(0))
         graph.query = query
         graph.boundary = boundary
+        graph.boundary_sparse = (h_index.to(torch.int32), query)
         return {"node_feature": self._run_layers(graph, boundary).transpose(1, 0)}
 
 
