@@ -659,7 +659,12 @@ struct CombineParams {
     int shortcut;
 };
 
-__global__ __launch_bounds__(kCbWaves * 64, 2) void combine_kernel(const CombineParams p) {
+// PF = true (large inputs): one wave per SIMD (up to 512 VGPRs); the NEXT tile's 16 KiB are fetched into registers
+// before the GEMM of the current tile and land while the matrix cores run -- with two waves per SIMD and no prefetch
+// the waves fall into step (both wait for HBM, then both want the MFMA pipe: 37 % MFMA busy, PMC).  PF = false: the
+// two-waves-per-SIMD form, for inputs of a few tiles per wave.
+template <bool PF>
+__global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(const CombineParams p) {
     extern __shared__ __attribute__((aligned(16))) float cb_lds[];
     const int lane = threadIdx.x & 63;
     const int wl = uniform(threadIdx.x >> 6);
@@ -686,21 +691,37 @@ __global__ __launch_bounds__(kCbWaves * 64, 2) void combine_kernel(const Combine
     if (p.gamma != nullptr && threadIdx.x < 128) gb[threadIdx.x] = threadIdx.x < 64 ? p.gamma[threadIdx.x] : p.beta[threadIdx.x - 64];
     __syncthreads();
 
-    for (long long t = wave_global; t < n_tiles; t += wave_total) {
-        const long long row0 = t * kCbRows;
-        const long long last = p.rows - 1;
-        // ---- stage the tile: 8 + 8 coalesced 1-KiB loads (4 rows each), rows past the end re-read the last row
+    const long long last = p.rows - 1;
+    f32x4 pa[8], pb[8];     // PF: the staged rows of the tile about to be processed
+    auto fetch = [&](long long t) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
-            long long gr = row0 + r;
+            long long gr = t * kCbRows + r;
             gr = gr < last ? gr : last;
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(p.input + gr * 64 + c);
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(p.update + gr * 64 + c);
-            *reinterpret_cast<f32x4 *>(tile + r * kCbStride + c) = a;
-            *reinterpret_cast<f32x4 *>(tile + r * kCbStride + 64 + c) = b;
+            pa[q] = *reinterpret_cast<const f32x4 *>(p.input + gr * 64 + c);
+            pb[q] = *reinterpret_cast<const f32x4 *>(p.update + gr * 64 + c);
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    if constexpr (PF) {
+        if (wave_global < n_tiles) fetch(wave_global);
+    }
+    for (long long t = wave_global; t < n_tiles; t += wave_total) {
+        const long long row0 = t * kCbRows;
+        // ---- stage the tile: 8 + 8 coalesced 1-KiB loads (4 rows each), rows past the end re-read the last row
+        if constexpr (!PF) fetch(t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
+            *reinterpret_cast<f32x4 *>(tile + r * kCbStride + c) = pa[q];
+            *reinterpret_cast<f32x4 *>(tile + r * kCbStride + 64 + c) = pb[q];
+        }
+        if constexpr (PF) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + wave_total < n_tiles) fetch(t + wave_total);     // in flight during the GEMM and the LayerNorm
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
 
         // ---- GEMM: acc_t[r] = D[row = (r&3) + 8(r>>2) + 4h][out = i + 32 t]
         f32x16 acc0, acc1;
@@ -1354,16 +1375,23 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
     p.out = out; p.rows = rows; p.eps = ln_eps; p.relu = relu; p.shortcut = shortcut;
     const long long n_tiles = (rows + kCbRows - 1) / kCbRows;
     long long blocks = (n_tiles + kCbWaves - 1) / kCbWaves;
-    const long long resident = (long long)di->n_cu * 2;
+    // at least ~4 tiles per wave: one workgroup per CU, one wave per SIMD, next tile prefetched under the GEMM
+    const bool prefetch = n_tiles >= (long long)di->n_cu * kCbWaves * 4;
+    const long long resident = (long long)di->n_cu * (prefetch ? 1 : 2);
     if (blocks > resident) blocks = resident;
     const size_t lds = (size_t)(kCbWaves * kCbTileFloats + 128) * sizeof(float);
     static bool attr_set[16] = {false};
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)blocks), dim3(kCbWaves * 64), lds, static_cast<hipStream_t>(stream), p);
+    if (prefetch)
+        hipLaunchKernelGGL(combine_kernel<true>, dim3((unsigned)blocks), dim3(kCbWaves * 64), lds, static_cast<hipStream_t>(stream), p);
+    else
+        hipLaunchKernelGGL(combine_kernel<false>, dim3((unsigned)blocks), dim3(kCbWaves * 64), lds, static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
 }
