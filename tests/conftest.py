@@ -18,3 +18,16 @@ def oracle():
     from oracle import oracle as mod
     mod.build()
     return mod
+
+
+@pytest.fixture(autouse=True)
+def _seed_global_generators(request):
+    """Every test starts from a seed derived from its own id, so results do not depend on which tests ran before
+    (module initialisers such as nn.Linear draw from torch's global generator)."""
+    import zlib
+    import numpy as np
+    import torch
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    yield

@@ -380,7 +380,9 @@ def test_fused_combine_matches_oracle_and_torch(oracle, rows, ln, relu, shortcut
 @pytest.mark.parametrize("case", ["skewed_hub", "small_weights", "many_relations_no_lds", "isolated_and_ragged_F"])
 def test_wide_id_variants_match_oracle(oracle, case):
     """Big-graph kernel variants (node ids outside the packed word; relation tile in LDS or, when it does not fit,
-    read through L2), forced on small graphs with `wide_ids=True`: forward and sum-backward, bit for bit."""
+    read through L2), forced on small graphs with `wide_ids=True`: forward and sum-backward, bit for bit.
+    (One chunk per wave: a four-chunks-per-wave form of these variants measured 5 % slower on the DRAM-bound
+    S-stress graph, whose rows hold 10 edges.)"""
     from ultra_torchdrug_amd import RelCSR, functional as UF
     kw, n, r, F = CASES[case]
     g = random_graph(seed=zlib.crc32(case.encode()) % 1000 + 3, n_node=n, n_rel=r, **dict(kw, unique=True))
@@ -409,9 +411,12 @@ def test_wide_id_variants_match_oracle(oracle, case):
 def test_fused_combine_backward_matches_autograd_of_the_reference_formulation(rows, ln, relu, shortcut):
     """functional.combine (fused forward + fused backward) against torch autograd on the reference's own chain
     cat -> Linear -> LayerNorm -> relu (+ input) (layer.py:386-392, model.py:126-127), evaluated in fp64 on the host.
-    fp32 tolerance: 2e-5 relative to the largest entry of each gradient (reductions over up to 65k rows)."""
+    fp32 tolerance: 2e-5 relative to the largest entry of each gradient (reductions over up to 65k rows).
+    ReLU is not differentiable at 0: rows holding a pre-activation within 1e-4 of 0 (where the fp32 and the fp64
+    chain may pick different sides) get a zero output gradient on both sides, so they do not enter any gradient."""
     from ultra_torchdrug_amd import functional as UF
     dev = _dev()
+    torch.manual_seed(rows + 17)        # nn.Linear's initialisation draws from the global generator
     gen = torch.Generator(device="cpu").manual_seed(rows + 17)
     x = torch.randn(rows, 64, generator=gen)
     u = torch.randn(rows, 64, generator=gen) * 2
@@ -431,6 +436,7 @@ def test_fused_combine_backward_matches_autograd_of_the_reference_formulation(ro
     if ln:
         ref = norm64(ref)
     if relu:
+        gout[(ref.detach().abs() < 1e-4).any(dim=1)] = 0.0
         ref = torch.relu(ref)
     if shortcut:
         ref = ref + x64
