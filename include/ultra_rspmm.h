@@ -213,6 +213,17 @@ int ultra_linear_forward_f32(const float *input, const float *weight, const floa
 int ultra_score_forward_f32(const float *hidden, const float *query, const float *w1, const float *b1, const float *w2,
                             const float *b2, float *out, int64_t n_node, int64_t batch, void *stream);
 
+/* Filtered ranking on the device, from filter LISTS instead of dense masks.
+ * Replaces: get_ranking, ultra/task.py:307-315 -- `sum((pos_pred <= pred) & mask, -1) + 1` -- together with the dense
+ * (B, N) boolean masks of ultra/task.py:65-100 (`mask[pos_index, truth_index] = 0`) that feed it.
+ *   pred       : fp32 [n_query, row_stride], the first n_cand entries of a row are the candidate scores
+ *   target     : int64 [n_query] index of the positive candidate
+ *   filt_ptr   : int32 [n_query + 1], filt_node : int32 [filt_ptr[n_query]] -- per query the DISTINCT candidates the
+ *                mask would set to 0 (known truths, the positive included when it is one); NULL: unfiltered ranking
+ *   rank       : int64 [n_query]  (1-based) */
+int ultra_filtered_rank(const float *pred, int64_t n_query, int64_t n_cand, int64_t row_stride, const int64_t *target,
+                        const int32_t *filt_ptr, const int32_t *filt_node, int64_t *rank, void *stream);
+
 
 /*
  * Native plan builder (rocPRIM radix sort + scans), replaces sparse.coalesce() + coo2csr that torchdrug runs inside

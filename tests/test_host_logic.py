@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     """libultra_rspmm.so loads without a GPU and exports each function include/ultra_rspmm.h declares."""
     from ultra_torchdrug_amd import _lib
     header = open(os.path.join(ROOT, "include", "ultra_rspmm.h")).read()
-    declared = sorted(set(re.findall(r"\b(ultra_(?:rspmm|combine|linear|score|relcsr)_\w+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(ultra_(?:rspmm|combine|linear|score|relcsr|filtered)_\w+)\s*\(", header)))
     assert len(declared) >= 8
     lib = _lib.load()
     for name in declared:
@@ -335,3 +335,27 @@ def test_reference_checkpoint_layout_loads(tmp_path):
     assert torch.equal(other.state_dict()["model.mlp.layers.0.weight"], src.state_dict()["model.mlp.layers.0.weight"])
     saved = checkpoint.save_checkpoint(dst, str(tmp_path / "out.pth"))
     assert set(saved["model"]) == set(src.state_dict())
+
+
+def test_filter_lists_equal_dense_masks():
+    """task.target_lists (CSR lists of the entities the filter clears, what the HIP rank kernel reads) describes
+    exactly the dense masks of task.target (task.py:65-100), including duplicate fact edges and empty lists."""
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    rng = np.random.default_rng(5)
+    n, r = 40, 3
+    triples = np.stack([rng.integers(0, n, 300), rng.integers(0, n, 300), rng.integers(0, r, 300)], axis=1)
+    triples = np.concatenate([triples, triples[:20]])            # duplicate edges
+    graph = Graph(torch.from_numpy(triples), num_node=n, num_relation=r)
+    task = build_ultra(r)
+    task.preprocess(graph)
+    batch = torch.from_numpy(np.concatenate([triples[:9], [[39, 38, 2], [0, 0, 0]]]))     # also unseen triples
+    mask, target = task.target(batch)
+    (ptr, node), target2 = task.target_lists(batch)
+    assert torch.equal(target, target2) and ptr.dtype == torch.int32 and node.dtype == torch.int32
+    dense = torch.ones(2 * len(batch), n, dtype=torch.bool)
+    for row in range(2 * len(batch)):
+        lst = node[ptr[row]:ptr[row + 1]].long()
+        assert len(torch.unique(lst)) == len(lst) and torch.equal(lst, torch.sort(lst).values)
+        dense[row, lst] = False
+    assert torch.equal(dense.view(len(batch), 2, n), mask)

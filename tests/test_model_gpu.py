@@ -184,3 +184,44 @@ def test_fused_sides_predict_equals_two_model_calls():
         plain = task.predict(batch.to(dev))
     assert fused.shape == plain.shape == (16, 2, 1200)
     assert torch.equal(fused, plain) and torch.equal(fused.cpu(), fused_cpu)
+
+
+@pytest.mark.parametrize("n_cand", [1, 37, 14541])
+def test_filtered_rank_kernel_equals_dense_mask_ranking_and_oracle(oracle, n_cand):
+    """ultra_filtered_rank (CSR filter lists) == sum((pos_pred <= pred) & mask, -1) + 1 (task.py:307-315) with the
+    dense mask == the C oracle; integer ranks, ties (quantised scores) and empty / full filter lists included."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n_cand)
+    rows = 23
+    pred = np.round(rng.standard_normal((rows, n_cand)) * 4).astype(np.float32) / 4          # many exact ties
+    target = rng.integers(0, n_cand, rows)
+    mask = rng.random((rows, n_cand)) < 0.8
+    mask[0] = True                       # nothing filtered
+    mask[1] = False                      # everything filtered -> rank 1
+    want = 1 + ((pred[np.arange(rows), target][:, None] <= pred) & mask).sum(axis=1)
+    assert np.array_equal(oracle.filtered_rank(pred, mask, target), want)
+    counts = (~mask).sum(axis=1)
+    ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(dev)
+    node = torch.from_numpy(np.nonzero(~mask)[1].astype(np.int32)).to(dev)
+    got = UF.filtered_rank(torch.from_numpy(pred).to(dev), torch.from_numpy(target).to(dev), ptr, node)
+    assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want)
+    unfiltered = UF.filtered_rank(torch.from_numpy(pred).to(dev), torch.from_numpy(target).to(dev))
+    assert np.array_equal(unfiltered.cpu().numpy(), 1 + (pred[np.arange(rows), target][:, None] <= pred).sum(axis=1))
+
+
+def test_rank_batch_on_device_equals_dense_mask_path():
+    """task.rank_batch (filter lists + HIP count) against get_ranking over the dense masks of task.target."""
+    task, triples = _build((1200, 9000, 12))
+    dev = torch.device("cuda:0")
+    task.to(dev)
+    rng = np.random.default_rng(3)
+    batch = torch.from_numpy(triples[rng.choice(len(triples), 16, replace=False)]).to(dev)
+    with torch.no_grad():
+        want = task.get_ranking(task.predict(batch), task.target(batch))
+        got = task.rank_batch(batch)
+        task.filtered_ranking = False
+        want_unfiltered = task.get_ranking(task.predict(batch), task.target(batch))
+        got_unfiltered = task.rank_batch(batch)
+    assert got.shape == (16, 2) and torch.equal(got, want) and torch.equal(got_unfiltered, want_unfiltered)
+    assert (want_unfiltered >= want).all()

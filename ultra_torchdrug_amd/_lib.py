@@ -58,6 +58,7 @@ EXPORTS = (
     "ultra_combine_backward_f32",
     "ultra_linear_forward_f32",
     "ultra_score_forward_f32",
+    "ultra_filtered_rank",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
     "ultra_relcsr_plan_temp_bytes",
@@ -128,6 +129,8 @@ def load():
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.ultra_score_forward_f32.restype = i32
     lib.ultra_score_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    lib.ultra_filtered_rank.restype = i32
+    lib.ultra_filtered_rank.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
     lib.ultra_relcsr_coalesce_temp_bytes.restype = sz
     lib.ultra_relcsr_coalesce_temp_bytes.argtypes = [i64]
     lib.ultra_relcsr_coalesce.restype = i32

@@ -231,6 +231,31 @@ def score_all_entities(hidden, query, w1, b1, w2, b2):
     return out
 
 
+def filtered_rank(pred, target, filt_ptr=None, filt_node=None):
+    """``sum((pos_pred <= pred) & mask, -1) + 1`` (``ultra/task.py:307-315``) with the mask given as per-row lists of
+    DISTINCT filtered candidates (``filt_ptr`` int32 ``(rows + 1,)``, ``filt_node`` int32) -- no dense ``(B, N)``
+    boolean.  ``pred``: fp32 ``(rows, N)``; ``target``: int64 ``(rows,)``; returns int64 ``(rows,)``."""
+    pred = pred.contiguous()
+    rows, n_cand = pred.shape
+    target = target.contiguous()
+    if target.dtype != torch.int64 or target.shape != (rows,) or pred.dtype != torch.float32:
+        raise RuntimeError("filtered_rank: pred fp32 (rows, N), target int64 (rows,)")
+    if filt_ptr is not None and (filt_ptr.dtype != torch.int32 or filt_node.dtype != torch.int32
+                                 or filt_ptr.shape != (rows + 1,) or not filt_ptr.is_contiguous()
+                                 or not filt_node.is_contiguous()):
+        raise RuntimeError("filtered_rank: filter lists must be int32 (rows + 1,) / int32 (n,)")
+    rank = torch.empty(rows, dtype=torch.int64, device=pred.device)
+    if rows == 0:
+        return rank
+    lib = _lib.load()
+    with torch.cuda.device(pred.device):
+        _lib.check(lib.ultra_filtered_rank(
+            pred.data_ptr(), rows, n_cand, n_cand, target.data_ptr(),
+            filt_ptr.data_ptr() if filt_ptr is not None else None,
+            filt_node.data_ptr() if filt_ptr is not None else None, rank.data_ptr(), _stream()))
+    return rank
+
+
 class _CombineFunction(torch.autograd.Function):
     """Fused epilogue with a fused backward (training).  Forward = ``combine_forward``; only the layer's inputs are
     saved.  Backward: ``libultra_rspmm`` recomputes z, applies the ReLU mask and LayerNorm-backward and reduces

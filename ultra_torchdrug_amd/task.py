@@ -18,6 +18,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import layer
 from .graph import Graph
 
 
@@ -138,6 +139,28 @@ class KnowledgeGraphCompletion(nn.Module):
         mask[pos_index, truth_index] = 0
         return mask
 
+    def _filter_pairs(self, graph, anchor_index, pos_r_index, anchor_col):
+        """The same truths as ``_calculate_mask`` as ``(pattern row, entity)`` pairs (duplicates possible)."""
+        any = -torch.ones_like(anchor_index)
+        cols = [anchor_index, any, pos_r_index] if anchor_col == 0 else [any, anchor_index, pos_r_index]
+        edge_index, num_truth = graph.match(torch.stack(cols, dim=-1))
+        return torch.repeat_interleave(num_truth), graph.edge_list[edge_index, 1 - anchor_col]
+
+    def target_lists(self, batch):
+        """``target`` without the dense ``(B, 2, N)`` mask: per ranking row ``2 b + side`` (side 0 = tail, 1 = head) the
+        sorted DISTINCT entities the mask would clear, as CSR lists ``(filt_ptr int32 (2B + 1,), filt_node int32)``,
+        plus the positives ``(B, 2)``."""
+        batch = self._select(batch)
+        pos_h_index, pos_t_index, pos_r_index = batch.t()
+        n, rows = self.graph.num_node, 2 * len(batch)
+        t_row, t_node = self._filter_pairs(self.graph, pos_h_index, pos_r_index, 0)
+        h_row, h_node = self._filter_pairs(self.graph, pos_t_index, pos_r_index, 1)
+        key = torch.unique(torch.cat([(2 * t_row) * n + t_node, (2 * h_row + 1) * n + h_node]))      # sorted, distinct
+        row = torch.div(key, n, rounding_mode="floor")
+        filt_ptr = torch.zeros(rows + 1, dtype=torch.long, device=batch.device)
+        torch.cumsum(torch.bincount(row, minlength=rows), 0, out=filt_ptr[1:])
+        return (filt_ptr.to(torch.int32), (key - row * n).to(torch.int32)), torch.stack([pos_t_index, pos_h_index], dim=1)
+
     def _calculate_t_mask(self, graph, pos_h_index, pos_r_index):
         return self._calculate_mask(graph, pos_h_index, pos_r_index, 0)
 
@@ -224,8 +247,16 @@ class KnowledgeGraphCompletion(nn.Module):
 
     @torch.no_grad()
     def rank_batch(self, batch):
-        """Scores, masks and ranks stay on the device; only ``(B, 2)`` int64 ranks are returned."""
-        return self.get_ranking(self.predict(batch), self.target(batch))
+        """Scores, filters and ranks stay on the device; only ``(B, 2)`` int64 ranks are returned.  On the device the
+        filter is a pair of CSR lists and the count runs in ``libultra_rspmm`` (``ultra_filtered_rank``); the dense
+        ``(B, 2, N)`` masks of ``target`` / ``get_ranking`` (task.py:279-315) remain the CPU / cross-check path."""
+        pred = self.predict(batch)
+        if pred.is_cuda and hasattr(layer.functional, "filtered_rank"):
+            lists, target = self.target_lists(batch)
+            if not self.filtered_ranking:
+                lists = (None, None)
+            return layer.functional.filtered_rank(pred.flatten(0, 1), target.flatten(), *lists).view(-1, 2)
+        return self.get_ranking(pred, self.target(batch))
 
     def evaluate(self, ranking):
         """task.py:317-351 on an int64 ``(n, 2)`` ranking tensor (column 0 = tail, 1 = head)."""
