@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--general", action="store_true")
     ap.add_argument("--backward", action="store_true")
     ap.add_argument("--boundary", action="store_true", help="forward with the fused `+ boundary` epilogue (add_rows), as inside a layer")
+    ap.add_argument("--relgraph", action="store_true", help="the workload's RELATION graph (2R nodes, 4 edge types) instead of the entity graph")
+    ap.add_argument("--weights", action="store_true", help="per-edge weights (0 for 1 %% of the edges, 1 elsewhere): the training step's edge removal")
     ap.add_argument("--hot", action="store_true", help="plans with the LDS hot-row cache (kernel VAR 4)")
     ap.add_argument("--combine", action="store_true", help="time the fused layer epilogue (forward, or fwd+bwd with --backward)")
     args = ap.parse_args()
@@ -32,9 +34,17 @@ def main():
     lib = U.require_library()
     lib.ultra_rspmm_force_general_path(1 if args.general else 0)
     dev = torch.device("cuda:0")
-    g = synthetic_kg(args.workload, device=dev).undirected(add_inverse=True)
+    g = synthetic_kg(args.workload, device=dev)
+    if args.relgraph:
+        from ultra_torchdrug_amd.rel_model import construct_relation_graph
+        g = construct_relation_graph(g)       # adds the inverse relations itself
+    else:
+        g = g.undirected(add_inverse=True)
     opts = dict(piece_len=args.piece, chunk_edges=args.chunk, hot_cache=args.hot)      # None: chosen from the edge count
     csr = U.RelCSR.from_edge_list(g.edge_list, g.edge_weight, g.num_node, g.num_relation, **opts)
+    if args.weights:
+        wgen = torch.Generator(device="cpu").manual_seed(1)
+        csr = csr.with_edge_weights((torch.rand(g.edge_list.shape[0], generator=wgen) > 0.01).float().to(dev))
     F = args.batch * 64
     gen = torch.Generator(device="cpu").manual_seed(0)
     relation = torch.randn(g.num_relation, F, generator=gen).to(dev)

@@ -823,6 +823,14 @@ bool g_no_quad = false;
 #define ULTRA_QUAD_U 8
 #endif
 constexpr int kQuadU = ULTRA_QUAD_U;   // edges per group in flight (quad_kernel)
+#ifndef ULTRA_QUAD_UW
+#define ULTRA_QUAD_UW 6
+#endif
+constexpr int kQuadUW = ULTRA_QUAD_UW;   // ... with per-edge weights: 8 would spill (128 VGPRs at 16 waves per CU)
+#ifndef ULTRA_QUAD_UX
+#define ULTRA_QUAD_UX 8
+#endif
+constexpr int kQuadUX = ULTRA_QUAD_UX;   // ... with the gathered matrix in LDS
 
 #define HIP_TRY(expr)                                   \
     do {                                                \
@@ -983,12 +991,12 @@ template <int KIND, int SUM, int MUL>
 int launch_quad_w(const PParams &p, bool unit_w, bool x_lds, int grid, size_t lds, hipStream_t stream) {
     if constexpr (KIND != KIND_DREL) {
         if (x_lds) {
-            if (unit_w) return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, true, kQuadU>, p, grid, lds, stream);
-            return launch_with_lds(quad_kernel<KIND, SUM, MUL, false, true, kQuadU>, p, grid, lds, stream);
+            if (unit_w) return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, true, kQuadUX>, p, grid, lds, stream);
+            return launch_with_lds(quad_kernel<KIND, SUM, MUL, false, true, kQuadUW>, p, grid, lds, stream);
         }
     }
     if (unit_w) return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, false, kQuadU>, p, grid, lds, stream);
-    return launch_with_lds(quad_kernel<KIND, SUM, MUL, false, false, kQuadU>, p, grid, lds, stream);
+    return launch_with_lds(quad_kernel<KIND, SUM, MUL, false, false, kQuadUW>, p, grid, lds, stream);
 }
 
 template <int KIND>
