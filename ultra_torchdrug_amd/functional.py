@@ -324,10 +324,14 @@ class _RSPMMFunction(torch.autograd.Function):
     """Counterpart of torchdrug's ``RSPMM{Add,Min,Max}{Mul,Add}Function`` autograd classes."""
 
     @staticmethod
-    def forward(ctx, sparse, relation, input, csr, sum, mul, add_rows=None):
-        # add_rows (sum only): `update + boundary` of layer.py:156,358 inside the kernel; its gradient is grad_out
-        out = rspmm_forward(csr, relation, input, sum, mul, add_rows=add_rows)
+    def forward(ctx, sparse, relation, input, csr, sum, mul, add_rows=None, b_node=None, b_value=None):
+        # add_rows (sum only): `update + boundary` of layer.py:156,358 inside the kernel; its gradient is grad_out.
+        # (b_node, b_value): the same boundary in sparse form -- the gradient of b_value[b] is row b_node[b] of
+        # query block b of grad_out (what scatter_add_'s backward would gather from the dense gradient)
+        boundary = None if b_node is None else (b_node, b_value.detach())
+        out = rspmm_forward(csr, relation, input, sum, mul, add_rows=add_rows, boundary=boundary)
         ctx.has_add_rows = add_rows is not None
+        ctx.b_node = b_node
         ctx.csr, ctx.sum, ctx.mul = csr, sum, mul
         ctx.sparse_meta = None
         if sparse is not None and sparse.requires_grad:
@@ -348,13 +352,24 @@ class _RSPMMFunction(torch.autograd.Function):
             # duplicates of one triple all receive its gradient
             d_sparse = torch.sparse_coo_tensor(indices, d_w[ctx.csr.edge_of_input], shape)
         d_add = output_grad if (ctx.has_add_rows and ctx.needs_input_grad[6]) else None
-        return d_sparse, d_relation, d_input, None, None, None, d_add
+        d_value = None
+        if ctx.b_node is not None and ctx.needs_input_grad[8]:
+            n_query = ctx.b_node.shape[0]
+            blocks = output_grad.view(output_grad.shape[0], n_query, -1)
+            d_value = blocks[ctx.b_node.long(), torch.arange(n_query, device=output_grad.device)]
+        return d_sparse, d_relation, d_input, None, None, None, d_add, None, d_value
 
 
-def rspmm_sum_plus(sparse, relation, input, add_rows, mul="mul"):
-    """``generalized_rspmm(..., sum="add") + add_rows`` with the addition inside the kernel (differentiable)."""
+def rspmm_sum_plus(sparse, relation, input, add_rows, mul="mul", boundary=None):
+    """``generalized_rspmm(..., sum="add") + add_rows`` with the addition inside the kernel (differentiable).
+    ``boundary = (node, value)`` instead of ``add_rows``: the boundary in sparse form (see :func:`rspmm_forward`),
+    differentiable in ``value``."""
     csr, sparse_leaf = _as_relcsr(sparse)
     _check_dense(csr, relation, input)
+    if boundary is not None:
+        if add_rows is not None:
+            raise RuntimeError("give the boundary either dense (add_rows) or sparse (boundary), not both")
+        return _RSPMMFunction.apply(sparse_leaf, relation, input, csr, "add", mul, None, boundary[0], boundary[1])
     return _RSPMMFunction.apply(sparse_leaf, relation, input, csr, "add", mul, add_rows)
 
 

@@ -192,8 +192,13 @@ class _RelationalConvBase(nn.Module):
         if kind in ("sum", "mean"):
             if fuse_bound:
                 update = functional.rspmm_forward(adjacency, relation_input, input, "add", mul, **bound_args)
-            elif bound and input.is_cuda and hasattr(functional, "rspmm_sum_plus"):
-                update = functional.rspmm_sum_plus(adjacency, relation_input, input, boundary, mul=mul)   # training
+            elif bound and input.is_cuda and hasattr(functional, "rspmm_sum_plus"):      # training
+                sparse_train = getattr(graph, "boundary_sparse", None)
+                if sparse_train is not None:
+                    update = functional.rspmm_sum_plus(adjacency, relation_input, input, None, mul=mul,
+                                                       boundary=sparse_train)
+                else:
+                    update = functional.rspmm_sum_plus(adjacency, relation_input, input, boundary, mul=mul)
             else:
                 update = rspmm(adjacency, relation_input, input, sum="add", mul=mul)
                 if bound:
