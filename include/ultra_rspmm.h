@@ -165,6 +165,7 @@ int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd_host, const float 
  * nn.LayerNorm, relu) and, when `shortcut` is set, the caller's `hidden + layer_input`
  * (ultra/model.py:126-127, ultra/rel_model.py:371-372).
  *   input, update, out : [rows, 64] fp32 (a row = one (node, query) pair);  weight [64, 128] = nn.Linear.weight;
+ *                        `out` may be the same buffer as `update` (each 32-row tile is read before it is written);
  *   bias [64];  ln_weight / ln_bias [64] or both NULL (no LayerNorm);  relu, shortcut: 0 / 1.
  * Forward only (inference); training keeps the ATen ops so that autograd sees them.
  */

@@ -48,7 +48,8 @@ class OracleFunctional:
 
     cpu_ok = True      # lets the layers route CPU tensors to `combine` below (the product itself is GPU-only)
 
-    def combine(self, input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False):
+    def combine(self, input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,
+                reuse_update=False):
         """Layer epilogue on the CPU: the oracle's C restatement (the HIP kernel's documented order) for inference,
         the reference's own torch chain (layer.py:386-392, model.py:126-127) when autograd is needed."""
         tensors = [t for t in (input, update, weight, bias, ln_weight, ln_bias) if t is not None]

@@ -167,9 +167,13 @@ def rspmm_backward_weight(csr, relation, input, output, output_grad, sum="add", 
     return d_w
 
 
-def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False):
+def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,
+                    reuse_update=False):
     """Fused ``combine`` (+ shortcut) of one layer, forward only: ``[input +] relu(LN(Linear(cat[input, update])))``
-    (``ultra/layer.py:386-392``, ``ultra/model.py:126-127``).  ``input`` / ``update``: ``(..., 64)`` fp32 on the GPU."""
+    (``ultra/layer.py:386-392``, ``ultra/model.py:126-127``).  ``input`` / ``update``: ``(..., 64)`` fp32 on the GPU.
+    ``reuse_update``: the caller owns ``update`` and does not need it afterwards -- the result is written over it
+    (every 32-row tile is read completely before it is written), which keeps a layer's working set at two
+    ``(N, B, 64)`` tensors instead of three."""
     if input.shape != update.shape or input.shape[-1] != 64 or tuple(weight.shape) != (64, 128):
         raise RuntimeError("combine_forward handles 64 -> 64 layers with a (64, 128) weight; got input %s, update %s, "
                            "weight %s" % (tuple(input.shape), tuple(update.shape), tuple(weight.shape)))
@@ -177,7 +181,7 @@ def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, l
     if any(t.dtype != torch.float32 or not t.is_cuda or t.device != input.device for t in tensors):
         raise RuntimeError("combine_forward needs fp32 tensors on one HIP device (no CPU fallback)")
     input, update = input.contiguous(), update.contiguous()
-    out = torch.empty_like(input)
+    out = update if reuse_update else torch.empty_like(input)
     rows = input.numel() // 64
     lib = _lib.load()
     with torch.cuda.device(input.device):
@@ -311,13 +315,16 @@ class _CombineFunction(torch.autograd.Function):
         return d_input, d_update, d_weight, d_bias, d_g, d_b, None, None, None
 
 
-def combine(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False):
+def combine(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,
+            reuse_update=False):
     """``combine`` + shortcut of one layer (``ultra/layer.py:386-392``, ``ultra/model.py:126-127``) as fused HIP
-    kernels, differentiable: same forward as :func:`combine_forward`, fused backward."""
+    kernels, differentiable: same forward as :func:`combine_forward`, fused backward.  ``reuse_update`` (inference
+    only): see :func:`combine_forward`."""
     tensors = [t for t in (input, update, weight, bias, ln_weight, ln_bias) if t is not None]
     if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
         return _CombineFunction.apply(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
-    return combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
+    return combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut,
+                           reuse_update=reuse_update and update.is_contiguous())
 
 
 class _RSPMMFunction(torch.autograd.Function):

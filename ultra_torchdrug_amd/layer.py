@@ -89,7 +89,8 @@ class _RelationalConvBase(nn.Module):
             ln = self.layer_norm
             return functional.combine(input, update, self.linear.weight, self.linear.bias,
                                       ln.weight if ln else None, ln.bias if ln else None,
-                                      ln.eps if ln else 1e-5, relu=self.activation is F.relu, shortcut=shortcut)
+                                      ln.eps if ln else 1e-5, relu=self.activation is F.relu, shortcut=shortcut,
+                                      reuse_update=True)       # `update` is this call's own temporary
         output = self.combine(input, update)
         return output + input if shortcut else output
 
