@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_RSPMM_ABI_VERSION 1
+#define ULTRA_RSPMM_ABI_VERSION 2
 
 /* sum= / mul= of generalized_rspmm (layer.py:134-167: sum in {"add","max","min"}, mul in {"mul","add"}) */
 enum ultra_sum_op { ULTRA_SUM_ADD = 0, ULTRA_SUM_MIN = 1, ULTRA_SUM_MAX = 2 };
@@ -179,18 +179,19 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
  * cat -> nn.Linear -> nn.LayerNorm -> relu chain (/root/reference/ultra/layer.py:386-392).
  *   grad_out                 : dL/d(out) [rows, 64]  (the shortcut's own pass-through, d_input += grad_out, is the caller's)
  *   d_z                      : OUT  dL/dz [rows, 64], z = Linear(cat[input, update]);  d_input = d_z . W[:, :64],
- *                              d_update = d_z . W[:, 64:]  and  d_bias = sum_rows d_z  are plain GEMM / reductions
+ *                              d_update = d_z . W[:, 64:]  are plain GEMMs
  *   d_ln_weight_partial,
  *   d_ln_bias_partial        : OUT  [n_ln_waves, 64] per-wave partial sums (sum over dim 0 gives the gradients)
  *   d_weight_partial         : OUT  [n_wgrad_waves, 64 * 128] per-wave partial slabs of d_weight
+ *   d_bias_partial           : OUT  [n_wgrad_waves, 64] per-wave column sums of d_z (d_bias partials), or NULL
  * ultra_combine_backward_waves() gives the two wave counts for `rows` on `device`.
  */
 int ultra_combine_backward_waves(int device, int64_t rows, int *n_ln_waves, int *n_wgrad_waves);
 int ultra_combine_backward_f32(const float *input, const float *update, const float *weight, const float *bias,
                                const float *ln_weight, const float *ln_bias, float ln_eps, int relu,
                                const float *grad_out, float *d_z, float *d_ln_weight_partial,
-                               float *d_ln_bias_partial, float *d_weight_partial, int64_t rows, int64_t dim,
-                               void *stream);
+                               float *d_ln_bias_partial, float *d_weight_partial, float *d_bias_partial, int64_t rows,
+                               int64_t dim, void *stream);
 
 
 /*

@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.ultra_rspmm_abi_version() == 1
+    version = int(re.search(r"#define ULTRA_RSPMM_ABI_VERSION (\d+)", header).group(1))
+    assert lib.ultra_rspmm_abi_version() == version == _lib.ABI_VERSION
     assert lib.ultra_rspmm_status_string(1).decode().startswith("unknown sum/mul")
     import ctypes
     assert ctypes.sizeof(_lib.UltraSegments) == 17 * 8          # struct layout of the header

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ULTRA_RSPMM_LIB: load another build of the same ABI (kernel A/B runs, tools/kbench.py)
 LIB_PATH = os.environ.get("ULTRA_RSPMM_LIB") or os.path.join(_HERE, "libultra_rspmm.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SUM_OPS = {"add": 0, "min": 1, "max": 2}
 MUL_OPS = {"mul": 0, "add": 1}
@@ -124,7 +124,7 @@ def load():
     lib.ultra_combine_backward_waves.restype = i32
     lib.ultra_combine_backward_waves.argtypes = [i32, i64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.ultra_combine_backward_f32.restype = i32
-    lib.ultra_combine_backward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, vp, vp, vp, vp, vp, i64, i64, vp]
+    lib.ultra_combine_backward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, vp, vp, vp, vp, vp, vp, i64, i64, vp]
     lib.ultra_linear_forward_f32.restype = i32
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.ultra_score_forward_f32.restype = i32

@@ -289,12 +289,14 @@ class _CombineFunction(torch.autograd.Function):
         dg_p = torch.empty(n_ln.value, 64, dtype=torch.float32, device=dev) if has_ln else None
         db_p = torch.empty(n_ln.value, 64, dtype=torch.float32, device=dev) if has_ln else None
         dw_p = torch.empty(n_wg.value, 64 * 128, dtype=torch.float32, device=dev)
+        dbias_p = torch.empty(n_wg.value, 64, dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         with torch.cuda.device(dev):
             _lib.check(lib.ultra_combine_backward_f32(
                 input_c.data_ptr(), update_c.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
                 ln_weight.contiguous().data_ptr() if has_ln else None, ln_bias.contiguous().data_ptr() if has_ln else None,
                 ln_eps, int(relu), grad_out.data_ptr(), d_z.data_ptr(), dg_p.data_ptr() if has_ln else None,
-                db_p.data_ptr() if has_ln else None, dw_p.data_ptr(), rows, 64, _stream()))
+                db_p.data_ptr() if has_ln else None, dw_p.data_ptr(),
+                dbias_p.data_ptr() if dbias_p is not None else None, rows, 64, _stream()))
         needs = ctx.needs_input_grad
         d_input = d_update = d_weight = d_bias = d_g = d_b = None
         if needs[0]:
@@ -307,7 +309,7 @@ class _CombineFunction(torch.autograd.Function):
         if needs[2]:
             d_weight = dw_p.sum(0).view(64, 128)
         if needs[3]:
-            d_bias = d_z.sum(0)
+            d_bias = dbias_p.sum(0)
         if has_ln and needs[4]:
             d_g = dg_p.sum(0)
         if has_ln and needs[5]:
