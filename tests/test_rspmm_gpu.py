@@ -167,6 +167,25 @@ def test_fused_boundary_epilogue(oracle):
         assert torch.equal(fused, want)
 
 
+def test_wide_batch_forward_and_backward_match_oracle(oracle):
+    """F = 4096 (the pre-training batch of 64 queries x 64 d, config 4): 64 column tiles, 8 per XCD."""
+    from ultra_torchdrug_amd import functional as UF
+    n, r, F = 700, 23, 4096
+    g = random_graph(seed=21, n_node=n, n_edge=12000, n_rel=r, skew=True, hub_row=3, hub_edges=900, unique=True)
+    relation, x = _inputs(9, n, r, F)
+    grad = np.random.default_rng(4).standard_normal((n, F)).astype(np.float32)
+    csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    csr = _relcsr(g, n, n, r)
+    dev = _dev()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    want = oracle.rspmm_forward(csr_o, relation, x, "add", "mul", piece=csr.piece_len)
+    got = UF.rspmm_forward(csr, t(relation), t(x), "add", "mul")
+    assert _same(got.cpu().numpy(), want)
+    d_rel_o, d_x_o = oracle.rspmm_backward(csr_o, relation, x, want, grad, "add", "mul", piece=csr.piece_len)
+    d_x, d_rel = UF.rspmm_backward(csr, t(relation), t(x), None, t(grad), "add", "mul")
+    assert _same(d_x.cpu().numpy(), d_x_o) and _same(d_rel.cpu().numpy(), d_rel_o)
+
+
 @pytest.mark.parametrize("flags", [0, 4, 1])
 def test_sparse_boundary_equals_dense_boundary(flags):
     """ultra_rspmm_forward_boundary_f32: the Bellman-Ford boundary as (node per query, value per query) instead of the
