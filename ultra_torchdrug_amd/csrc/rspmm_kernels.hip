@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     if (p.add_rows != nullptr) v = reduce<RED>(v, p.add_rows[(long long)r * F + col]);
                     else if (p.bnode != nullptr) v = reduce<RED>(v, (r == b_node) ? b_val : 0.0f);
                 }
-                p.out[(long long)r * F + col] = v;
+                __builtin_nontemporal_store(v, &p.out[(long long)r * F + col]);   // streaming: keep the gathered rows in L2
             }
         };
         auto contribute = [&](float acc, float rv, float gv, float w) -> float {
