@@ -39,6 +39,10 @@ constexpr int kWaves = kBlock / 64;
 #define ULTRA_UNROLL 8
 #endif
 constexpr int kUnroll = ULTRA_UNROLL;   // gathers in flight per wave
+#ifndef ULTRA_UNROLL_BIG
+#define ULTRA_UNROLL_BIG 8
+#endif
+constexpr int kUnrollBig = ULTRA_UNROLL_BIG;   // ... for the big-graph variants of packed_kernel (DRAM gathers; 16 measured 3 % slower); <= PACK_SLACK
 constexpr int kXcd = 8;
 constexpr int kFixUnroll = 16;
 constexpr int kMaxLdsBytes = 156 * 1024;   // leave a little of the 160 KiB
@@ -327,7 +331,8 @@ struct PParams {
 //        plan lists the n_hot most frequently gathered nodes (KGs are heavy-tailed: the 140 hottest sources of the
 //        FB15k237-shaped graph feed 49 % of its edges); the word's node field holds the cache slot for those and
 //        n_hot + node for the rest, so a hot edge costs a ds_read_b32 instead of a trip through TA / L2.
-template <int KIND, int SUM, int MUL, bool UNIT_W, int VAR>
+// UN: gathers in flight per wave (8; 16 measured slower for cache-resident and for DRAM-resident graphs alike).
+template <int KIND, int SUM, int MUL, bool UNIT_W, int VAR, int UN = kUnroll>
 __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
     constexpr bool X_LDS = (VAR == 1);
     constexpr bool BIG = (VAR == 2 || VAR == 3);
@@ -450,12 +455,12 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
             uint32_t cur = 0;
             float acc = identity<RED>();
             int e0 = 0;
-            for (; e0 + kUnroll <= n; e0 += kUnroll) {
-                uint32_t m[kUnroll];
-                float wv[kUnroll], gv[kUnroll], rv[kUnroll];
-                uint32_t m2[kUnroll];
+            for (; e0 + UN <= n; e0 += UN) {
+                uint32_t m[UN];
+                float wv[UN], gv[UN], rv[UN];
+                uint32_t m2[UN];
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     m[u] = meta[e0 + u];
                     m2[u] = 0;
                     if constexpr (TWO_GATHERS || BIG) m2[u] = meta2[e0 + u];
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     if constexpr (!UNIT_W) wv[u] = wts[e0 + u];
                 }
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     if constexpr (TWO_GATHERS) {
                         gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
                     } else if constexpr (BIG) {
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     rv[u] = 0.0f;
                     if constexpr (NEEDS_REL && REL_GLOBAL)
                         rv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_rel, voff, (m[u] >> 8) * p.row_bytes, 0));
@@ -482,12 +487,12 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                         rv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                               rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
                 }
-                if ((m[kUnroll - 1] & 0xffu) == cur) {   // whole batch in the current row (always true for pieces)
+                if ((m[UN - 1] & 0xffu) == cur) {   // whole batch in the current row (always true for pieces)
 #pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) acc = contribute(acc, rv[u], gv[u], wv[u]);
+                    for (int u = 0; u < UN; ++u) acc = contribute(acc, rv[u], gv[u], wv[u]);
                 } else {
 #pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) {
+                    for (int u = 0; u < UN; ++u) {
                         const uint32_t dl = m[u] & 0xffu;
                         if (dl != cur) {
                             store_row(row_base + (int)cur, acc);
@@ -499,13 +504,13 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     }
                 }
             }
-            if (e0 < n) {   // tail: fewer than kUnroll edges
+            if (e0 < n) {   // tail: fewer than UN edges
                 const int rem = n - e0;
-                uint32_t m[kUnroll];
-                float wv[kUnroll], gv[kUnroll], rv[kUnroll];
-                uint32_t m2[kUnroll];
+                uint32_t m[UN];
+                float wv[UN], gv[UN], rv[UN];
+                uint32_t m2[UN];
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     const int e = e0 + min(u, rem - 1);
                     m[u] = meta[e];
                     m2[u] = 0;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     if constexpr (!UNIT_W) wv[u] = wts[e];
                 }
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     if constexpr (TWO_GATHERS) {
                         gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
                     } else if constexpr (BIG) {
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     rv[u] = 0.0f;
                     if constexpr (NEEDS_REL && REL_GLOBAL)
                         rv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_rel, voff, (m[u] >> 8) * p.row_bytes, 0));
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                                                               rsrc, voff, (m[u] >> p.src_shift) * p.row_bytes, 0));
                 }
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     if (u < rem) {
                         const uint32_t dl = m[u] & 0xffu;
                         if (dl != cur) {
@@ -948,10 +953,11 @@ int launch_with_lds(Kern kern, const Params &p, int grid, size_t lds, hipStream_
 
 template <int KIND, int SUM, int MUL>
 int launch_packed_w(const PParams &p, bool unit_w, int var, int grid, size_t lds, hipStream_t stream) {
-#define ULTRA_VAR(V)                                                                                         \
-    if (var == V) {                                                                                          \
-        if (unit_w) return launch_with_lds(packed_kernel<KIND, SUM, MUL, true, V>, p, grid, lds, stream);   \
-        return launch_with_lds(packed_kernel<KIND, SUM, MUL, false, V>, p, grid, lds, stream);              \
+#define ULTRA_VAR(V)                                                                                                  \
+    if (var == V) {                                                                                                   \
+        constexpr int UN = (V == 2 || V == 3) ? kUnrollBig : kUnroll;                                                 \
+        if (unit_w) return launch_with_lds(packed_kernel<KIND, SUM, MUL, true, V, UN>, p, grid, lds, stream);        \
+        return launch_with_lds(packed_kernel<KIND, SUM, MUL, false, V, UN>, p, grid, lds, stream);                   \
     }
     if constexpr (KIND != KIND_DREL) {
         ULTRA_VAR(1)
