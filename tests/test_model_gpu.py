@@ -115,6 +115,19 @@ def test_graphed_predict_equals_eager():
     assert task.model.check_indices          # the reference's asserts are back on for eager calls
 
 
+def test_evaluate_with_graph_replay_equals_eager_evaluation():
+    """engine.evaluate: the hipGraph-replayed batches and the ragged eager tail give the ranks of the eager loop."""
+    from ultra_torchdrug_amd import engine
+    task, triples = _build("S-tiny")
+    dev = torch.device("cuda:0")
+    task.to(dev)
+    queries = torch.from_numpy(triples[:37])                       # 4 full batches of 8 + a tail of 5
+    metric_g, ranking_g = engine.evaluate(task, queries, batch_size=8, graphed=True)
+    metric_e, ranking_e = engine.evaluate(task, queries, batch_size=8, graphed=False)
+    assert ranking_g.shape == (37, 2) and torch.equal(ranking_g, ranking_e)
+    assert all(torch.equal(metric_g[k], metric_e[k]) for k in metric_e)
+
+
 def test_inductive_zero_shot_inference_matches_oracle_path():
     """configs[0] of BASELINE.json in miniature: weights meet a graph with OTHER entities at test time (inductive
     split, ultra/task.py:525-634); HIP path vs the same model with the CPU oracle as operator."""

@@ -108,13 +108,21 @@ class GraphedPredict:
 
 
 @torch.no_grad()
-def evaluate(task, triples, batch_size=16):
+def evaluate(task, triples, batch_size=16, graphed=None):
     """Filtered ranking of ``triples`` ((n, 3) rows of (h, t, r)) sharded over ranks; every rank returns the
-    metrics of the WHOLE set.  Only int64 ranks cross ranks."""
+    metrics of the WHOLE set.  Only int64 ranks cross ranks.  ``graphed`` (default: on a GPU, when the shard holds at
+    least two full batches): ``predict`` is captured once and replayed as a hipGraph for every full batch."""
     device = task.device
     mine = shard_indices(len(triples))
     local = triples[mine].to(device)
-    ranks = [task.rank_batch(local[i:i + batch_size]) for i in range(0, len(local), batch_size)]
+    if graphed is None:
+        graphed = device.type == "cuda" and len(local) >= 2 * batch_size and not task.training
+    replay = GraphedPredict(task, local[:batch_size]) if graphed and len(local) >= batch_size else None
+    ranks = []
+    for i in range(0, len(local), batch_size):
+        batch = local[i:i + batch_size]
+        pred = replay(batch) if replay is not None and len(batch) == batch_size else None
+        ranks.append(task.rank_batch(batch, pred=pred))
     ranks = torch.cat(ranks) if ranks else torch.zeros(0, 2, dtype=torch.long, device=device)
     ranking = gather_variable(ranks)
     return task.evaluate(ranking), ranking

@@ -246,11 +246,12 @@ class KnowledgeGraphCompletion(nn.Module):
         return torch.sum(pos_pred <= pred, dim=-1) + 1
 
     @torch.no_grad()
-    def rank_batch(self, batch):
+    def rank_batch(self, batch, pred=None):
         """Scores, filters and ranks stay on the device; only ``(B, 2)`` int64 ranks are returned.  On the device the
         filter is a pair of CSR lists and the count runs in ``libultra_rspmm`` (``ultra_filtered_rank``); the dense
         ``(B, 2, N)`` masks of ``target`` / ``get_ranking`` (task.py:279-315) remain the CPU / cross-check path."""
-        pred = self.predict(batch)
+        if pred is None:        # (a caller that replays `predict` as a hipGraph passes its scores in)
+            pred = self.predict(batch)
         if pred.is_cuda and hasattr(layer.functional, "filtered_rank"):
             lists, target = self.target_lists(batch)
             if not self.filtered_ranking:
