@@ -238,3 +238,32 @@ def test_rank_batch_on_device_equals_dense_mask_path():
         got_unfiltered = task.rank_batch(batch)
     assert got.shape == (16, 2) and torch.equal(got, want) and torch.equal(got_unfiltered, want_unfiltered)
     assert (want_unfiltered >= want).all()
+
+
+def test_graphed_train_step_equals_eager_train_step():
+    """engine.GraphedTrainStep (forward + backward replayed as one hipGraph, negatives and edge mask fed through
+    static buffers) takes the same steps as engine.train_step: same losses, same parameters after 3 steps."""
+    import copy
+    from ultra_torchdrug_amd import engine
+    task, triples = _build("S-tiny")
+    task.num_negative = 16
+    dev = torch.device("cuda:0")
+    task.to(dev).train()
+    twin = copy.deepcopy(task)
+    batches = [torch.from_numpy(triples[i:i + 8]).to(dev) for i in (0, 8, 16, 24)]
+
+    opt_e = torch.optim.AdamW(task.parameters(), lr=1e-3)
+    losses_e = []
+    for b in batches[1:]:
+        torch.manual_seed(int(b[0, 0]))              # negatives are drawn with torch.rand on the device
+        losses_e.append(engine.train_step(task, opt_e, b)[0].item())
+
+    opt_g = torch.optim.AdamW(twin.parameters(), lr=1e-3)
+    step = engine.GraphedTrainStep(twin, opt_g, batches[0])
+    losses_g = []
+    for b in batches[1:]:
+        torch.manual_seed(int(b[0, 0]))
+        losses_g.append(step(b)[0].item())
+    assert losses_g == losses_e
+    for (k, a), (_, b) in zip(task.named_parameters(), twin.named_parameters()):
+        assert torch.equal(a, b), k

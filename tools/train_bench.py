@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--rebuild", action="store_true")
+    ap.add_argument("--graphed", action="store_true", help="forward + backward replayed as one hipGraph (engine.GraphedTrainStep)")
     args = ap.parse_args()
     from ultra_torchdrug_amd import engine
     from ultra_torchdrug_amd.data import synthetic_triples, DEFAULT_SEED
@@ -38,12 +39,17 @@ def main():
     data = torch.from_numpy(triples).to(dev)
     rng = np.random.default_rng(0)
     losses = []
+    graphed = None
+    if args.graphed:
+        idx = torch.from_numpy(rng.choice(len(triples), args.batch, replace=False)).to(dev)
+        graphed = engine.GraphedTrainStep(task, opt, data[idx])
     for i in range(3 + args.steps):
         if i == 3:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         idx = torch.from_numpy(rng.choice(len(triples), args.batch, replace=False)).to(dev)
-        loss, _ = engine.train_step(task, opt, data[idx])
+        loss, _ = graphed(data[idx]) if graphed is not None else engine.train_step(task, opt, data[idx])
+        loss = loss.clone()
         losses.append(loss)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
@@ -52,7 +58,7 @@ def main():
     E_rel = task.rel_graphs[0].relcsr.n_edges
     msgs = (6 * E + 6 * E_rel) * args.batch * 3          # forward + d_input + d_relation
     print("%s B=%d %s: %.2f ms/step, %.2e edge messages/s (fwd+bwd), loss %.4f -> %.4f"
-          % (args.workload, args.batch, "rebuild" if args.rebuild else "zero-weight", ms, msgs / (ms * 1e-3),
+          % (args.workload, args.batch, ("rebuild" if args.rebuild else "zero-weight") + (", hipGraph" if args.graphed else ""), ms, msgs / (ms * 1e-3),
              losses[0].item(), losses[-1].item()))
 
 

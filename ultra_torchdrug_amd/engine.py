@@ -107,6 +107,62 @@ class GraphedPredict:
         return self.static_pred
 
 
+class GraphedTrainStep:
+    """Forward + backward of one fine-tuning step (``ultra/engine.py:62-92``) for a fixed batch size as ONE hipGraph.
+    A step is ~800 launches, most of them tiny, and their host-side issue cost exceeds the GPU time of the kernels.
+    What has data-dependent shapes stays eager and feeds static buffers: the strict negatives (``nonzero`` over the
+    filter masks, task.py:102-118) and the mask of the batch's own edges (``graph.match``, model.py:57-74).  The
+    gradient all-reduce and the optimizer step follow the replay eagerly (``train_step`` semantics)."""
+
+    def __init__(self, task, optimizer, example_batch, warmup=3):
+        assert example_batch.is_cuda and task.training
+        self.task, self.optimizer = task, optimizer
+        model = task.model
+        self.static_batch = example_batch.clone()
+        self.static_neg, self.static_keep = self._eager_inputs(self.static_batch)
+        self.static_neg, self.static_keep = self.static_neg.clone(), self.static_keep.clone()
+        model.check_indices = False
+        task._static_negative, model._static_keep = self.static_neg, self.static_keep
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):             # plans, kernel attributes, workspaces, allocator
+                    optimizer.zero_grad(set_to_none=True)
+                    loss, _ = task(self.static_batch)
+                    loss.backward()
+            torch.cuda.current_stream().wait_stream(side)
+            optimizer.zero_grad(set_to_none=True)   # the captured backward allocates the gradients in the graph's pool
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
+                self.static_loss, self.static_metric = task(self.static_batch)
+                self.static_loss.backward()
+        finally:
+            model.check_indices = True
+            task._static_negative, model._static_keep = None, None
+
+    def _eager_inputs(self, batch):
+        task, model = self.task, self.task.model
+        task._static_negative, model._static_keep = None, None
+        h_index, t_index, r_index = task.training_indices(batch)
+        keep = model.easy_edge_mask(task.fact_graph, h_index, t_index, r_index)
+        half = len(batch) // 2
+        neg = torch.cat([t_index[:half, 1:], h_index[half:, 1:]])
+        return neg, keep
+
+    def __call__(self, batch):
+        """One step on ``batch`` (same shape as the example): returns ``(loss, metrics averaged over ranks)``."""
+        assert batch.shape == self.static_batch.shape
+        neg, keep = self._eager_inputs(batch)
+        self.static_batch.copy_(batch)
+        self.static_neg.copy_(neg)
+        self.static_keep.copy_(keep)
+        self.graph.replay()
+        allreduce_gradients(self.task)
+        self.optimizer.step()
+        return self.static_loss.detach(), reduce_metrics(self.static_metric)
+
+
 @torch.no_grad()
 def evaluate(task, triples, batch_size=16, graphed=None):
     """Filtered ranking of ``triples`` ((n, 3) rows of (h, t, r)) sharded over ranks; every rank returns the

@@ -116,7 +116,10 @@ class Graph:
         edge_weight = torch.as_tensor(edge_weight, dtype=torch.float, device=self.device)
         if edge_weight.shape != self.edge_weight.shape:
             raise ValueError("edge_weight must have one entry per edge")
-        g = Graph(self.edge_list, edge_weight, self.num_node, self.num_relation)
+        g = Graph.__new__(Graph)            # same (already validated) edge list: no range check, no host sync
+        g.edge_list, g.edge_weight = self.edge_list, edge_weight
+        g.num_node, g.num_relation = self.num_node, self.num_relation
+        g.requires_grad, g._relcsr, g._adjacency = False, None, None
         g._match_index = self._match_index
         if self.edge_list.shape[1] == 3:
             g._relcsr = self.relcsr.with_edge_weights(edge_weight)

@@ -53,6 +53,9 @@ class TransferNBFNet(nn.Module):
     def easy_edge_mask(self, graph, h_index, t_index, r_index=None):
         """model.py:57-73: True for the edges that stay -- every edge except the batch's own positives (and their
         reverse when ``remove_one_hop``)."""
+        static = getattr(self, "_static_keep", None)
+        if static is not None:          # engine.GraphedTrainStep: computed eagerly, the captured step reads this buffer
+            return static
         if self.remove_one_hop:
             h_ext = torch.cat([h_index, t_index], dim=-1)
             t_ext = torch.cat([t_index, h_index], dim=-1)

@@ -170,6 +170,9 @@ class KnowledgeGraphCompletion(nn.Module):
     @torch.no_grad()
     def _strict_negative(self, pos_h_index, pos_t_index, pos_r_index):
         """task.py:102-118: first half of the batch corrupts tails, second half heads; negatives are non-edges."""
+        static = getattr(self, "_static_negative", None)
+        if static is not None:          # engine.GraphedTrainStep: drawn eagerly, the captured step reads this buffer
+            return static
         half = len(pos_h_index) // 2
         t_mask = self._calculate_t_mask(self.fact_graph, pos_h_index[:half], pos_r_index[:half])
         neg_t = variadic_sample(t_mask.nonzero()[:, 1], t_mask.sum(dim=-1), self.num_negative)
@@ -221,13 +224,21 @@ class KnowledgeGraphCompletion(nn.Module):
                                           all_entities=len(neg_index) == self.num_entity))
             return torch.stack([torch.cat(t_preds, dim=-1), torch.cat(h_preds, dim=-1)], dim=1)   # (B, 2, N)
 
-        neg_index = self._strict_negative(pos_h_index, pos_t_index, pos_r_index)    # training
+        h_index, t_index, r_index = self.training_indices(batch)
+        return self.model(self.fact_graph, rel_inputs, h_index, t_index, r_index, all_loss=all_loss, metric=metric)
+
+    def training_indices(self, batch):
+        """task.py:264-274: ``(B, 1 + num_negative)`` index grids, column 0 = the positive triple, the rest strict
+        negatives (tails corrupted in the first half of the batch, heads in the second)."""
+        pos_h_index, pos_t_index, pos_r_index = batch.t()
+        batch_size = len(batch)
+        neg_index = self._strict_negative(pos_h_index, pos_t_index, pos_r_index)
         h_index = pos_h_index.unsqueeze(-1).repeat(1, self.num_negative + 1)
         t_index = pos_t_index.unsqueeze(-1).repeat(1, self.num_negative + 1)
         r_index = pos_r_index.unsqueeze(-1).repeat(1, self.num_negative + 1)
         t_index[:batch_size // 2, 1:] = neg_index[:batch_size // 2]
         h_index[batch_size // 2:, 1:] = neg_index[batch_size // 2:]
-        return self.model(self.fact_graph, rel_inputs, h_index, t_index, r_index, all_loss=all_loss, metric=metric)
+        return h_index, t_index, r_index
 
     def target(self, batch):
         """task.py:279-295: filter masks over the FULL graph and the true tail / head of each triple."""
@@ -283,7 +294,7 @@ class KnowledgeGraphCompletion(nn.Module):
     # ------------------------------------------------------------------ training loss (task.py:160-195)
     def forward(self, batch, all_loss=None, metric=None):
         batch = self._select(batch)
-        all_loss = torch.tensor(0, dtype=torch.float32, device=batch.device)
+        all_loss = torch.zeros((), dtype=torch.float32, device=batch.device)
         metric = {}
         pred = self.predict(batch, all_loss, metric)
         for criterion, weight in self.criterion.items():
