@@ -138,6 +138,23 @@ class TransferNBFNet(nn.Module):
             output = torch.cat([hiddens[-1], node_query], dim=-1)
         return {"node_feature": output, "step_graphs": step_graphs}
 
+    def score_all_entities(self, graph, rel_query_list, h_index, r_index):
+        """Scores ``(Q, N)`` of every entity as the tail of the queries ``(h_index[q], r_index[q], ?)``, both 1-D and
+        ALREADY in tail form (``r_index`` in ``[0, 2R)`` over the graph with inverse edges): what ``forward`` computes
+        for full-batch evaluation once ``negative_sample_to_tail`` has flipped the head-corrupted rows
+        (model.py:76-83,166-167) -- without materialising the ``(Q, N)`` index grids.  Inference only; ``None`` when the
+        fused score head does not cover this model (the caller then goes through ``forward``)."""
+        if not graph.num_relation or not self._fused_head_ok(h_index, None):
+            return None
+        self.query = rel_query_list[0]
+        for i, conv in enumerate(self.layers):
+            conv.relation = rel_query_list[i + 1] if len(rel_query_list) > 1 else rel_query_list[0]
+        graph = self._undirected(graph)
+        parts = self.bellmanford(graph, h_index, r_index, want_feature=False)
+        first, second = self.mlp.layers
+        return layer.functional.score_all_entities(parts["hidden"], parts["query"], first.weight, first.bias,
+                                                   second.weight, second.bias)
+
     def forward(self, graph, rel_query_list, h_index, t_index, r_index=None, all_loss=None, metric=None,
                 all_entities=False):
         """model.py:145-194: scores of shape ``h_index.shape``.  ``all_entities=True`` is the caller's promise that
@@ -207,14 +224,17 @@ class TransferNBFNet(nn.Module):
     def _fused_score_ok(self, graph, t_index, metric):
         """The fused score head covers the shipped head (64-d hidden + 64-d query -> 128 -> 128 -> 1, relu),
         inference, every entity a candidate."""
+        return self._fused_head_ok(t_index, metric) and t_index.shape[1] == graph.num_node
+
+    def _fused_head_ok(self, index, metric):
         F_ = layer.functional
         mlp = self.mlp
-        dev_ok = t_index.is_cuda or getattr(F_, "cpu_ok", False)
+        dev_ok = index.is_cuda or getattr(F_, "cpu_ok", False)
         return (dev_ok and hasattr(F_, "score_all_entities") and not torch.is_grad_enabled() and metric is None
                 and not self.symmetric and not self.concat_hidden and self.dims[0] == 64 and self.dims[-1] == 64
                 and len(mlp.layers) == 2 and mlp.layers[0].in_features == 128 and mlp.layers[0].out_features == 128
                 and mlp.layers[1].out_features == 1 and mlp.activation is torch.nn.functional.relu
-                and not mlp.short_cut and t_index.shape[1] == graph.num_node)
+                and not mlp.short_cut)
 
     def _undirected(self, graph):
         """``graph.undirected(add_inverse=True)`` (model.py:166), memoised on the graph object: the reference

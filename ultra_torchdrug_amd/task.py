@@ -199,6 +199,12 @@ class KnowledgeGraphCompletion(nn.Module):
         rel_inputs = self.relation_representations(pos_r_index, all_loss, metric)
 
         if all_loss is None and self.full_batch_eval and self.fuse_sides:         # evaluation, both sides at once
+            # rows 0..B-1: (h, r, ?);  rows B..2B-1: (?, r, t) in tail form = (t, r + R, ?)  (model.py:76-83)
+            rel2 = [torch.cat([r, r]) for r in rel_inputs]
+            pred = self.model.score_all_entities(self.fact_graph, rel2, torch.cat([pos_h_index, pos_t_index]),
+                                                 torch.cat([pos_r_index, pos_r_index + self.fact_graph.num_relation]))
+            if pred is not None:
+                return pred.view(2, batch_size, self.num_entity).transpose(0, 1).contiguous()    # (B, 2, N)
             all_row = torch.arange(self.num_entity, device=batch.device).unsqueeze(0).expand(batch_size, -1)
             pos_h, pos_t = (x.unsqueeze(-1).expand(-1, self.num_entity) for x in (pos_h_index, pos_t_index))
             h_index = torch.cat([pos_h, all_row])           # rows B..2B-1 are head-corrupted: the model flips them
