@@ -193,6 +193,13 @@ int ultra_combine_backward_f32(const float *input, const float *update, const fl
                                float *d_ln_bias_partial, float *d_weight_partial, float *d_bias_partial, int64_t rows,
                                int64_t dim, void *stream);
 
+/* d_input and d_update of the same backward in one pass over d_z:
+ *     d_input = [grad_out +] d_z . weight[:, :64]      d_update = d_z . weight[:, 64:]
+ * (what autograd derives for cat -> nn.Linear, ultra/layer.py:386-387, plus the shortcut's pass-through,
+ * ultra/model.py:126-127); grad_out NULL when the layer has no shortcut.  All [rows, 64] fp32; weight [64, 128]. */
+int ultra_combine_dxdu_f32(const float *d_z, const float *weight, const float *grad_out, float *d_input, float *d_update,
+                           int64_t rows, int64_t dim, void *stream);
+
 
 /*
  * out[rows, out_dim] = relu?( input[rows, in_dim] . weight[out_dim, in_dim]^T + bias ) in a documented summation order

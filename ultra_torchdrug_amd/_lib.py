@@ -56,6 +56,7 @@ EXPORTS = (
     "ultra_combine_forward_f32",
     "ultra_combine_backward_waves",
     "ultra_combine_backward_f32",
+    "ultra_combine_dxdu_f32",
     "ultra_linear_forward_f32",
     "ultra_score_forward_f32",
     "ultra_filtered_rank",
@@ -125,6 +126,8 @@ def load():
     lib.ultra_combine_backward_waves.argtypes = [i32, i64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.ultra_combine_backward_f32.restype = i32
     lib.ultra_combine_backward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    lib.ultra_combine_dxdu_f32.restype = i32
+    lib.ultra_combine_dxdu_f32.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp]
     lib.ultra_linear_forward_f32.restype = i32
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.ultra_score_forward_f32.restype = i32

@@ -299,12 +299,19 @@ class _CombineFunction(torch.autograd.Function):
                 dbias_p.data_ptr() if dbias_p is not None else None, rows, 64, _stream()))
         needs = ctx.needs_input_grad
         d_input = d_update = d_weight = d_bias = d_g = d_b = None
-        if needs[0]:
+        if needs[0] and needs[1]:       # both activation gradients: one pass over d_z instead of two GEMMs
+            d_input, d_update = torch.empty_like(input_c), torch.empty_like(update_c)
+            with torch.cuda.device(dev):
+                _lib.check(lib.ultra_combine_dxdu_f32(
+                    d_z.data_ptr(), weight.contiguous().data_ptr(), grad_out.data_ptr() if shortcut else None,
+                    d_input.data_ptr(), d_update.data_ptr(), rows, 64, _stream()))
+            d_input, d_update = d_input.view_as(input), d_update.view_as(update)
+        elif needs[0]:
             if shortcut:        # d_input = grad_out + d_z . W[:, :64] in one GEMM call (beta = 1)
                 d_input = torch.addmm(grad_out.view(rows, 64), d_z, weight[:, :64]).view_as(input)
             else:
                 d_input = torch.mm(d_z, weight[:, :64]).view_as(input)
-        if needs[1]:
+        if needs[1] and d_update is None:
             d_update = torch.mm(d_z, weight[:, 64:]).view_as(update)
         if needs[2]:
             d_weight = dw_p.sum(0).view(64, 128)
