@@ -222,6 +222,17 @@ int ultra_linear_forward_f32(const float *input, const float *weight, const floa
 int ultra_score_forward_f32(const float *hidden, const float *query, const float *w1, const float *b1, const float *w2,
                             const float *b2, float *out, int64_t n_node, int64_t batch, void *stream);
 
+/* The relation projections of all entity layers in one launch:
+ *     out[l][r, b, :] = w2[l] . relu( w1[l] . relation[b, r, :] + b1[l] ) + b2[l]
+ * = `relation_projection` (2-layer MLP) of GeneralizedRelationalConvNBFMod followed by the (B, R, D) -> (R, B*D)
+ * transpose (ultra/layer.py:228,318-319,325-326), which ultra/model.py:120-130 triggers once per layer.
+ *   relation : fp32 [batch, n_rel, 64];  w1 / b1 / w2 / b2 / out : HOST arrays of n_layers DEVICE pointers
+ *   (weights [64, 64] as nn.Linear.weight, biases [64], out[l] [n_rel, batch, 64]).  Bit-identical to two
+ *   ultra_linear_forward_f32 calls + the transpose. */
+int ultra_relation_project_f32(const float *relation, const float *const *w1, const float *const *b1,
+                               const float *const *w2, const float *const *b2, float *const *out, int64_t n_layers,
+                               int64_t batch, int64_t n_rel, int64_t dim, void *stream);
+
 /* Filtered ranking on the device, from filter LISTS instead of dense masks.
  * Replaces: get_ranking, ultra/task.py:307-315 -- `sum((pos_pred <= pred) & mask, -1) + 1` -- together with the dense
  * (B, N) boolean masks of ultra/task.py:65-100 (`mask[pos_index, truth_index] = 0`) that feed it.

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     """libultra_rspmm.so loads without a GPU and exports each function include/ultra_rspmm.h declares."""
     from ultra_torchdrug_amd import _lib
     header = open(os.path.join(ROOT, "include", "ultra_rspmm.h")).read()
-    declared = sorted(set(re.findall(r"\b(ultra_(?:rspmm|combine|linear|score|relcsr|filtered)_\w+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(ultra_(?:rspmm|combine|linear|score|relcsr|filtered|relation)_\w+)\s*\(", header)))
     assert len(declared) >= 8
     lib = _lib.load()
     for name in declared:

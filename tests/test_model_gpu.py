@@ -267,3 +267,23 @@ def test_graphed_train_step_equals_eager_train_step():
     assert losses_g == losses_e
     for (k, a), (_, b) in zip(task.named_parameters(), twin.named_parameters()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("batch,n_rel", [(1, 1), (3, 37), (32, 474)])
+def test_grouped_relation_projection_equals_per_layer_path(batch, n_rel):
+    """ultra_relation_project_f32 (all layers' projections + transposes in one launch) against two
+    ultra_linear_forward_f32 calls and the (B, R, D) -> (R, B * D) transpose per layer, and against nn.Linear."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(batch * 1000 + n_rel)
+    relation = torch.randn(batch, n_rel, 64, generator=gen).to(dev)
+    layers = [(torch.nn.Linear(64, 64).to(dev), torch.nn.Linear(64, 64).to(dev)) for _ in range(6)]
+    with torch.no_grad():
+        got = UF.relation_project(relation, [(a.weight, a.bias, b.weight, b.bias) for a, b in layers])
+        assert len(got) == 6
+        for (a, b), table in zip(layers, got):
+            hidden = UF.linear_forward(relation, a.weight, a.bias, relu=True)
+            want = UF.linear_forward(hidden, b.weight, b.bias).transpose(0, 1).flatten(1)
+            assert table.shape == (n_rel, batch * 64) and torch.equal(table, want)
+            ref = b(torch.relu(a(relation))).transpose(0, 1).flatten(1)
+            torch.testing.assert_close(table, ref, rtol=2e-5, atol=2e-5)

@@ -59,6 +59,7 @@ EXPORTS = (
     "ultra_combine_dxdu_f32",
     "ultra_linear_forward_f32",
     "ultra_score_forward_f32",
+    "ultra_relation_project_f32",
     "ultra_filtered_rank",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
@@ -132,6 +133,8 @@ def load():
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.ultra_score_forward_f32.restype = i32
     lib.ultra_score_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    lib.ultra_relation_project_f32.restype = i32
+    lib.ultra_relation_project_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]
     lib.ultra_filtered_rank.restype = i32
     lib.ultra_filtered_rank.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
     lib.ultra_relcsr_coalesce_temp_bytes.restype = sz

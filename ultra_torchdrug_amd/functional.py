@@ -235,6 +235,37 @@ def score_all_entities(hidden, query, w1, b1, w2, b2):
     return out
 
 
+def relation_project(relation, weights):
+    """All layers' relation projections in one launch.  ``relation``: fp32 ``(B, R, 64)``; ``weights``: one
+    ``(w1, b1, w2, b2)`` per layer (``nn.Linear`` weights ``(64, 64)`` / biases ``(64,)`` of the 2-layer
+    ``relation_projection`` MLP, ``ultra/layer.py:228,318-319``).  Returns one ``(R, B * 64)`` table per layer
+    -- ``relation_projection(relation).transpose(0, 1).flatten(1)`` (``layer.py:325-326``), bit for bit."""
+    import ctypes
+    relation = relation.contiguous()
+    if relation.dim() != 3 or relation.shape[-1] != 64 or relation.dtype != torch.float32 or not relation.is_cuda:
+        raise RuntimeError("relation_project: fp32 (B, R, 64) on a HIP device, got %s" % (tuple(relation.shape),))
+    batch, n_rel, _ = relation.shape
+    n = len(weights)
+    keep, cols = [], [[], [], [], []]
+    for layer_weights in weights:
+        for k, t in enumerate(layer_weights):
+            t = t.detach().contiguous()
+            if t.dtype != torch.float32 or t.device != relation.device or t.shape != ((64, 64) if k % 2 == 0 else (64,)):
+                raise RuntimeError("relation_project: 64 -> 64 -> 64 fp32 projections only")
+            keep.append(t)
+            cols[k].append(t.data_ptr())
+    outs = [torch.empty(n_rel, batch * 64, dtype=torch.float32, device=relation.device) for _ in range(n)]
+    if n == 0 or relation.numel() == 0:
+        return outs
+    arr = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
+    lib = _lib.load()
+    with torch.cuda.device(relation.device):
+        _lib.check(lib.ultra_relation_project_f32(
+            relation.data_ptr(), arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]),
+            arr([o.data_ptr() for o in outs]), n, batch, n_rel, 64, _stream()))
+    return outs
+
+
 def filtered_rank(pred, target, filt_ptr=None, filt_node=None):
     """``sum((pos_pred <= pred) & mask, -1) + 1`` (``ultra/task.py:307-315``) with the mask given as per-row lists of
     DISTINCT filtered candidates (``filt_ptr`` int32 ``(rows + 1,)``, ``filt_node`` int32) -- no dense ``(B, N)``

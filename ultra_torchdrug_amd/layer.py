@@ -172,7 +172,11 @@ class _RelationalConvBase(nn.Module):
         batch_size = len(graph.query)
         input = input.flatten(1)
         boundary = graph.boundary.flatten(1)
-        relation_input = self._relation_table(graph, batch_size).flatten(1)    # (R, B*D)
+        tables = getattr(graph, "relation_tables", None)       # all layers' tables from one launch (model.bellmanford)
+        if tables is not None and id(self) in tables:
+            relation_input = tables[id(self)]
+        else:
+            relation_input = self._relation_table(graph, batch_size).flatten(1)    # (R, B*D)
         adjacency = graph.relcsr        # cached plans of graph.adjacency.transpose(0, 1)
         func = self.aggregate_func
         bound = not func.endswith("_nobound")

@@ -114,6 +114,7 @@ class TransferNBFNet(nn.Module):
         # this instead of the dense tensor in every layer's epilogue)
         graph.boundary_sparse = (h_index.to(torch.int32), query)
 
+        graph.relation_tables = self._relation_tables(bs)
         hiddens, step_graphs = [], []
         layer_input = boundary
         for conv in self.layers:
@@ -137,6 +138,30 @@ class TransferNBFNet(nn.Module):
         else:
             output = torch.cat([hiddens[-1], node_query], dim=-1)
         return {"node_feature": output, "step_graphs": step_graphs}
+
+    def _relation_tables(self, batch_size):
+        """Inference on the GPU with per-query relation representations and the shipped 64 -> 64 -> 64 projections:
+        the ``(R, B * D)`` relation tables of ALL layers from one launch (each layer otherwise issues two linear
+        launches and a transposing copy of its own, layer.py:318-326).  ``None``: every layer builds its own."""
+        F_ = layer.functional
+        convs = list(self.layers)
+        if not hasattr(F_, "relation_project") or torch.is_grad_enabled() or not convs:
+            return None
+        relation = getattr(convs[0], "relation", None)
+        if relation is None or not relation.is_cuda or relation.dim() != 3 or relation.shape[0] != batch_size \
+                or relation.shape[-1] != 64 or relation.dtype != torch.float32:
+            return None
+        weights = []
+        for conv in convs:
+            mlp = getattr(conv, "relation_projection", None)
+            ok = (getattr(conv, "project", False) and conv.relation is relation and mlp is not None
+                  and len(mlp.layers) == 2 and not mlp.short_cut and mlp.activation is torch.nn.functional.relu
+                  and all(l.in_features == 64 and l.out_features == 64 and l.bias is not None for l in mlp.layers))
+            if not ok:
+                return None
+            weights.append((mlp.layers[0].weight, mlp.layers[0].bias, mlp.layers[1].weight, mlp.layers[1].bias))
+        tables = F_.relation_project(relation, weights)
+        return {id(conv): table for conv, table in zip(convs, tables)}
 
     def score_all_entities(self, graph, rel_query_list, h_index, r_index):
         """Scores ``(Q, N)`` of every entity as the tail of the queries ``(h_index[q], r_index[q], ?)``, both 1-D and
