@@ -70,7 +70,21 @@ class CustomNBFNet(nn.Module):
         feature_dim = hidden_dims[-1] * (len(hidden_dims) if concat_hidden else 1) + input_dim
         self.mlp = layer.MLP(feature_dim, [feature_dim] * (num_mlp_layer - 1) + [hidden_dims[-1]])   # unused in forward
 
+    def _tiled_tables(self, graph, batch_size):
+        """Inference: the query-independent relation tables of all layers (``relation.weight.repeat(1, B)``,
+        layer.py:125-126) tiled by ONE copy instead of one per layer."""
+        convs = list(self.layers)
+        if torch.is_grad_enabled() or not convs or any(conv.dependent for conv in convs):
+            return None
+        weights = [conv.relation.weight for conv in convs]
+        if any(w.shape != weights[0].shape or not w.is_cuda for w in weights):
+            return None
+        n_rel, dim = weights[0].shape
+        tiled = torch.stack(weights).unsqueeze(2).expand(-1, -1, batch_size, -1).reshape(len(convs), n_rel, batch_size * dim)
+        return {id(conv): tiled[i] for i, conv in enumerate(convs)}
+
     def _run_layers(self, graph, boundary):
+        graph.relation_tables = self._tiled_tables(graph, boundary.shape[1])
         layer_input = boundary
         for conv in self.layers:
             # shortcut (rel_model.py:371-372) applied inside the layer call
