@@ -360,3 +360,22 @@ def test_filter_lists_equal_dense_masks():
         assert len(torch.unique(lst)) == len(lst) and torch.equal(lst, torch.sort(lst).values)
         dense[row, lst] = False
     assert torch.equal(dense.view(len(batch), 2, n), mask)
+
+
+def test_missing_library_fails_loudly():
+    """No HIP library -> the operator raises (no CPU / PyTorch fallback): checked in a child process whose
+    ULTRA_RSPMM_LIB points at a file that does not exist."""
+    import subprocess
+    import sys
+    code = (
+        "import torch, ultra_torchdrug_amd as U\n"
+        "from ultra_torchdrug_amd import _lib\n"
+        "try:\n"
+        "    U.require_library()\n"
+        "except _lib.UltraLibraryError as err:\n"
+        "    print('RAISED', type(err).__name__)\n"
+        "else:\n"
+        "    print('LOADED')\n")
+    env = dict(os.environ, ULTRA_RSPMM_LIB="/nonexistent/libultra_rspmm.so", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "RAISED UltraLibraryError" in out.stdout, out.stdout + out.stderr
