@@ -154,11 +154,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # ULTRA_BENCH_SHARE_GPU=1 (development only): all ranks on the visible GPU(s), gloo instead of RCCL -- lets the
+    # multi-rank code path (sharding, barriers, max-over-ranks timing) run on a one-GPU box
+    share = os.environ.get("ULTRA_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, "launch N ranks with torch.distributed.run for --gpus N"
 
     import ultra_torchdrug_amd as U
@@ -284,7 +292,7 @@ def main():
             eager_ms = 1e3 * elapsed / args.steps
     UF.rspmm_forward = real_forward
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
