@@ -102,8 +102,9 @@ int ultra_rspmm_event_create(void **event_host);
 int ultra_rspmm_event_destroy(void *event);
 int ultra_rspmm_event_elapsed_ms(void *start_event, void *stop_event, float *ms_host);
 
-/* Test/bench knob (process-wide): bit 0 forces the general kernel where the packed fast path applies, bit 1 keeps
- * the packed kernel from staging a small gathered matrix in LDS. */
+/* Test/bench knob (process-wide): bit 0 forces the general kernel where the packed fast paths apply, bit 1 keeps
+ * them from staging a small gathered matrix in LDS, bit 2 selects one chunk per wave (packed_kernel) where four
+ * chunks per wave (quad_kernel) would run.  All paths return identical bits. */
 int ultra_rspmm_force_general_path(int on);
 
 /* Scratch bytes a call over `seg` with row width F needs (piece partial sums). */
