@@ -118,7 +118,8 @@ size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg_host, int64_t F);
  *   add_rows  : optional [n_rows, F] or NULL.  When given, the epilogue the reference applies right
  *               after the call is fused: sum=add -> out + add_rows (layer.py:156,358),
  *               sum=max -> max(out, add_rows) (layer.py:162,364), sum=min -> min(out, add_rows).
- * Empty rows give 0 (add), +inf (min), -inf (max).
+ * Empty rows give 0 (add), FLT_MAX (min), -FLT_MAX (max): torchdrug's NaryMin / NaryMax start from
+ * std::numeric_limits<scalar_t>::max() / lowest(), finite values.
  */
 int ultra_rspmm_forward_f32(const ultra_segments *fwd_host, const float *relation, const float *input,
                             const float *add_rows, float *out, void *workspace, size_t workspace_bytes,
@@ -135,6 +136,21 @@ int ultra_rspmm_forward_boundary_f32(const ultra_segments *fwd, const float *rel
                                      const int32_t *boundary_node, const float *boundary_value, int64_t block, float *out,
                                      void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_rel, int64_t F,
                                      int sum_op, int mul_op, void *stream);
+
+/* The FIRST Bellman-Ford layer: `input` IS the boundary (ultra/model.py:116-120, ultra/rel_model.py:365-369), zero outside
+ * row boundary_node[b] of query block b.  For sum = add, mul = mul (DistMult messages, summed: the shipped configuration)
+ * every edge whose source row is zero contributes w * (rel * 0) = +-0 and can be skipped without changing one bit of the
+ * sums, so only the out-edges of the boundary nodes are visited: identical result to
+ * ultra_rspmm_forward_boundary_f32(fwd, relation, <dense boundary>, boundary_node, boundary_value, ...) for finite
+ * relation values, from deg_out(boundary nodes) edges instead of E.
+ *   by_src    : the d_input plan of the graph (edges sorted by (src, dst, rel)); its `weight` / `piece_len` are used
+ *   src_ptr   : int32 [n_src + 1] first edge of every source node in that order
+ *   fwd_rank  : int32 [E] position of each of those edges inside its destination row in FORWARD-plan order (which piece
+ *               of a split row the edge belongs to: rank / piece_len)
+ *   block     : must be 64;  out [n_dst, F] is written completely (zero fill included). */
+int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_ptr, const int32_t *fwd_rank,
+                             const float *relation, const int32_t *boundary_node, const float *boundary_value,
+                             int64_t block, float *out, int64_t n_dst, int64_t n_rel, int64_t F, void *stream);
 
 /*
  * Gradients of the call above w.r.t. input and relation
@@ -168,7 +184,7 @@ int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd_host, const float 
  *   input, update, out : [rows, 64] fp32 (a row = one (node, query) pair);  weight [64, 128] = nn.Linear.weight;
  *                        `out` may be the same buffer as `update` (each 32-row tile is read before it is written);
  *   bias [64];  ln_weight / ln_bias [64] or both NULL (no LayerNorm);  relu, shortcut: 0 / 1.
- * Forward only (inference); training keeps the ATen ops so that autograd sees them.
+ * Forward of the epilogue; its backward (training) is ultra_combine_backward_f32 + ultra_combine_dxdu_f32 below.
  */
 int ultra_combine_forward_f32(const float *input, const float *update, const float *weight, const float *bias,
                               const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
@@ -244,6 +260,36 @@ int ultra_relation_project_f32(const float *relation, const float *const *w1, co
  *   rank       : int64 [n_query]  (1-based) */
 int ultra_filtered_rank(const float *pred, int64_t n_query, int64_t n_cand, int64_t row_stride, const int64_t *target,
                         const int32_t *filt_ptr, const int32_t *filt_node, int64_t *rank, void *stream);
+
+
+/*
+ * Per-step index work from SORTED KEY ARRAYS instead of dense (B, N) masks (csrc/sampler.inc).  A graph keeps, per
+ * direction, the sorted DISTINCT int64 keys  (anchor * n_rel + rel) * n_node + other  of its triples: for tail
+ * prediction anchor = head, other = tail; for head prediction anchor = tail, other = head.  All three calls only
+ * enqueue work: no allocation, no host synchronisation, capturable into a hipGraph.
+ *
+ * ultra_filtered_rank_keys: get_ranking (ultra/task.py:307-315) with the filter mask of ultra/task.py:65-100 looked up
+ *   in `keys`:  rank = 1 + #{c : pos <= pred[c]} - #{c completes (anchor_q, rel_q, ?) : pos <= pred[c]}.
+ *   Query q reads pred + q * row_stride (n_cand = n_node scores), target[q * target_stride], anchor / rel
+ *   [q * index_stride] and writes rank[q * rank_stride]; keys == NULL: unfiltered ranking.
+ * ultra_strict_negative: strict negative sampling (ultra/task.py:102-118) without mask.nonzero(): out[q, s] is the
+ *   floor(rand[q, s] * n_free_q)-th entity in ascending order that does NOT complete (anchor_q, rel_q, ?) -- the entity
+ *   torchdrug's variadic_sample picks for the same uniform numbers.  rand fp32 [n_query, n_sample] in [0, 1).
+ * ultra_edge_removal_weights: remove_easy_edges (ultra/model.py:57-74, remove_one_hop = False) as edge weights: the
+ *   three plans of the graph WITH inverse edges get weight arrays (n_edges + slack floats each) equal to their own
+ *   weights (1.0 when NULL, 1.0 in the slack) except 0.0 at every edge (h, t, r) / (t, h, r + n_base_rel) of the
+ *   n_pattern triples that exists -- duplicates of a triple are one coalesced edge, so all of them go, as in the
+ *   reference.  Triples that are not edges (the negatives of the batch) change nothing.
+ */
+int ultra_filtered_rank_keys(const float *pred, int64_t n_query, int64_t n_cand, int64_t row_stride, const int64_t *target,
+                             int64_t target_stride, const int64_t *keys, int64_t n_keys, const int64_t *anchor,
+                             const int64_t *rel, int64_t index_stride, int64_t n_rel, int64_t *rank, int64_t rank_stride,
+                             void *stream);
+int ultra_strict_negative(const int64_t *keys, int64_t n_keys, const int64_t *anchor, const int64_t *rel, int64_t n_query,
+                          int64_t n_rel, int64_t n_node, const float *rand, int64_t n_sample, int64_t *out, void *stream);
+int ultra_edge_removal_weights(const ultra_segments *fwd, const ultra_segments *by_src, const ultra_segments *by_rel,
+                               const int64_t *h, const int64_t *t, const int64_t *r, int64_t n_pattern,
+                               int64_t n_base_rel, float *w_fwd, float *w_src, float *w_rel, int64_t slack, void *stream);
 
 
 /*

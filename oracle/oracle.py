@@ -155,10 +155,10 @@ def rspmm_materialised(dst, src, rel, w, relation, x, n_rows, sum="add", mul="mu
         out = np.zeros((n_rows, F), dtype=dtype)
         np.add.at(out, dst, message)                          # scatter_add :276
     elif sum == "max":
-        out = np.full((n_rows, F), -np.inf, dtype=dtype)
+        out = np.full((n_rows, F), np.finfo(np.float32).min, dtype=dtype)    # numeric_limits::lowest()
         np.maximum.at(out, dst, message)                      # scatter_max :280
     elif sum == "min":
-        out = np.full((n_rows, F), np.inf, dtype=dtype)
+        out = np.full((n_rows, F), np.finfo(np.float32).max, dtype=dtype)    # numeric_limits::max()
         np.minimum.at(out, dst, message)                      # scatter_min :285
     else:
         raise ValueError(sum)
@@ -168,7 +168,8 @@ def rspmm_materialised(dst, src, rel, w, relation, x, n_rows, sum="add", mul="mu
 def rspmm_python(dst, src, rel, w, relation, x, n_rows, sum="add", mul="mul"):
     """Plain loops in Python floats (fp64); tiny graphs only."""
     F = len(x[0])
-    ident = {"add": 0.0, "min": float("inf"), "max": float("-inf")}[sum]
+    fmax = float(np.finfo(np.float32).max)
+    ident = {"add": 0.0, "min": fmax, "max": -fmax}[sum]
     out = [[ident] * F for _ in range(n_rows)]
     for k in range(len(dst)):
         wk = 1.0 if w is None else float(w[k])

@@ -24,7 +24,8 @@
  *       in that sorted order and accumulated sequentially,
  *           x = BinaryOp(relation[rel], input[col]);  y = value * x;
  *           out = NaryOp(out, y);
- *       with out starting at 0 (add), +inf (min), -inf (max); the backward
+ *       with out starting at 0 (add), FLT_MAX (min), -FLT_MAX (max) -- NaryMin /
+ *       NaryMax ::zero = std::numeric_limits<scalar_t>::max() / lowest(); the backward
  *       forms grad * dOut/dy * dy/dx * dx/d{input,relation} per edge, where
  *       dOut/dy is 1 for add and (out == y) for min/max.
  * Decisions taken because torchdrug cannot be consulted are marked DECISION.
@@ -38,6 +39,7 @@
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -68,8 +70,8 @@ static inline float nary_fwd(int sum_op, float acc, float y) {
 }
 static inline float nary_identity(int sum_op) {
     if (sum_op == ORACLE_SUM_ADD) return 0.0f;
-    if (sum_op == ORACLE_SUM_MIN) return INFINITY; /* DECISION: empty row -> +inf */
-    return -INFINITY;                               /* DECISION: empty row -> -inf */
+    if (sum_op == ORACLE_SUM_MIN) return FLT_MAX;  /* DECISION: empty row -> numeric_limits::max()    */
+    return -FLT_MAX;                                /* DECISION: empty row -> numeric_limits::lowest() */
 }
 
 int oracle_abi_version(void) { return 1; }

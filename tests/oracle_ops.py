@@ -1,8 +1,8 @@
-"""Test infrastructure: run the package's model stack on CPU with the rspmm operator replaced by the CPU oracle.
+"""Test infrastructure: run the package's model stack on CPU with every operator replaced by the CPU oracle.
 
-The product's ``generalized_rspmm`` refuses CPU tensors (no fallback).  For end-to-end parity tests the layers'
-``functional`` module attribute is swapped for this oracle-backed operator, so the SAME Python model code yields
-the CPU-oracle scores that the HIP path is compared with.
+The product's operators refuse CPU tensors (no fallback).  For end-to-end parity tests an oracle-backed object with
+the complete backend interface (``ultra_torchdrug_amd/backend.py``) is installed with ``backend.use``, so the SAME
+Python model code yields the CPU-oracle numbers that the HIP path is compared with.
 """
 import contextlib
 
@@ -31,7 +31,8 @@ class _OracleRSPMM(torch.autograd.Function):
 
 
 class OracleFunctional:
-    """Drop-in for ``ultra_torchdrug_amd.functional`` inside ``layer.py`` (only ``generalized_rspmm`` is used)."""
+    """The backend interface of ``ultra_torchdrug_amd/backend.py`` on CPU tensors, every operator through the oracle
+    (C restatement) or the reference's own torch formulation."""
 
     def __init__(self, piece):
         self.piece = piece
@@ -46,7 +47,9 @@ class OracleFunctional:
                                                        relcsr.rel_id.cpu().numpy(), w, n_dst, n_src, n_rel))
         return self._cache[key][1]
 
-    cpu_ok = True      # lets the layers route CPU tensors to `combine` below (the product itself is GPU-only)
+    @staticmethod
+    def accepts(tensor):
+        return not tensor.is_cuda
 
     def combine(self, input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,
                 reuse_update=False):
@@ -85,15 +88,86 @@ class OracleFunctional:
         piece = sparse.piece_len if self.piece is None else self.piece       # None: each plan's own piece length
         return _OracleRSPMM.apply(relation.contiguous(), input.contiguous(), self._csr(sparse), sum, mul, piece)
 
+    @staticmethod
+    def _dense_boundary(boundary, n_rows):
+        """(node (B,), value (B, D)) -> the (N, B * D) tensor scatter_add_ builds in ultra/model.py:106-107."""
+        node, value = boundary
+        dense = torch.zeros(n_rows, *value.shape, dtype=value.dtype)
+        index = node.long().view(1, -1, 1).expand(1, *value.shape)
+        return dense.scatter_add(0, index, value.unsqueeze(0)).flatten(1)
+
+    def rspmm_forward(self, csr, relation, input, sum="add", mul="mul", add_rows=None, boundary=None):
+        """The fused boundary epilogue of the HIP kernels, unfused: layer.py:156,162,358,364 as written."""
+        out = self.generalized_rspmm(csr, relation, input, sum=sum, mul=mul)
+        if boundary is not None:
+            add_rows = self._dense_boundary(boundary, out.shape[0])
+        if add_rows is None:
+            return out
+        return out + add_rows if sum == "add" else (torch.max(out, add_rows) if sum == "max" else torch.min(out, add_rows))
+
+    def rspmm_sum_plus(self, sparse, relation, input, add_rows, mul="mul", boundary=None):
+        out = self.generalized_rspmm(sparse, relation, input, sum="add", mul=mul)
+        return out + (add_rows if boundary is None else self._dense_boundary(boundary, out.shape[0]))
+
+    @staticmethod
+    def frontier_supported(sum, mul, F):
+        return sum == "add" and mul == "mul" and F % 64 == 0
+
+    def rspmm_frontier(self, csr, relation, boundary):
+        """The first layer the long way round: the dense boundary as input (what the reference does)."""
+        dense = self._dense_boundary(boundary, csr.shape[1])
+        return self.rspmm_forward(csr, relation, dense, "add", "mul", boundary=boundary)
+
+    def relation_project(self, relation, weights):
+        """layer.py:318-319,325-326 per layer: two linear layers and the (B, R, D) -> (R, B * D) transpose."""
+        outs = []
+        for w1, b1, w2, b2 in weights:
+            hidden = self.linear_forward(relation.contiguous(), w1, b1, relu=True)
+            outs.append(self.linear_forward(hidden, w2, b2).transpose(0, 1).flatten(1).contiguous())
+        return outs
+
+    @staticmethod
+    def remove_triples(graph, h, t, r, n_base_rel):
+        """model.py:57-74 + :166 on the graph with inverse edges: weight 0 for (h, t, r) and (t, h, r + R)."""
+        n, rels = graph.num_node, graph.num_relation
+        key = lambda a, b, c: (a * n + b) * rels + c
+        gone = torch.cat([key(h.reshape(-1), t.reshape(-1), r.reshape(-1)),
+                          key(t.reshape(-1), h.reshape(-1), r.reshape(-1) + n_base_rel)])
+        e = graph.edge_list
+        keep = ~torch.isin(key(e[:, 0], e[:, 1], e[:, 2]), gone)
+        return graph.reweighted(graph.edge_weight * keep)
+
+    @staticmethod
+    def strict_negatives(keys, anchor, rel, n_rel, n_node, rand):
+        """task.py:102-118 literally: dense mask, nonzero, variadic_sample with the given uniform numbers."""
+        rows = len(anchor)
+        mask = torch.ones(rows, n_node, dtype=torch.bool)
+        base = (anchor * n_rel + rel) * n_node
+        lo, hi = torch.searchsorted(keys, base), torch.searchsorted(keys, base + n_node)
+        for q in range(rows):
+            mask[q, keys[lo[q]:hi[q]] - base[q]] = False
+        candidates, sizes = mask.nonzero()[:, 1], mask.sum(dim=-1)
+        index = (rand * sizes.unsqueeze(-1)).long()
+        index = torch.minimum(index, (sizes - 1).unsqueeze(-1)) + (sizes.cumsum(0) - sizes).unsqueeze(-1)
+        return candidates[index]
+
+    @staticmethod
+    def filtered_rank_keys(pred, target, keys, anchor, rel, n_rel):
+        """task.py:307-315 with the dense mask of task.py:65-100 rebuilt from the keys."""
+        rows, n_node = pred.shape
+        mask = np.ones((rows, n_node), dtype=bool)
+        if keys is not None:
+            base = (anchor * n_rel + rel) * n_node
+            lo, hi = torch.searchsorted(keys, base), torch.searchsorted(keys, base + n_node)
+            for q in range(rows):
+                mask[q, (keys[lo[q]:hi[q]] - base[q]).numpy()] = False
+        return torch.from_numpy(O.filtered_rank(pred.contiguous().numpy(), mask, target.numpy()))
+
 
 @contextlib.contextmanager
 def oracle_rspmm(piece=None):
     """Inside the context the layers aggregate with the CPU oracle: ``piece=None`` -> the kernels' summation order
     (every RelCSR's own ``piece_len``), ``piece=0`` -> the reference's strictly sequential order."""
-    from ultra_torchdrug_amd import layer
-    saved = layer.functional
-    layer.functional = OracleFunctional(piece)
-    try:
-        yield
-    finally:
-        layer.functional = saved
+    from ultra_torchdrug_amd import backend
+    with backend.use(OracleFunctional(piece)) as ops:
+        yield ops

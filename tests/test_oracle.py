@@ -16,7 +16,8 @@ MULS = ["mul", "add"]
 
 
 def _num(a):
-    return np.array([[float(v) for v in row] for row in a], dtype=np.float32)
+    special = {"flt_max": np.finfo(np.float32).max, "-flt_max": np.finfo(np.float32).min}
+    return np.array([[special[v] if isinstance(v, str) else float(v) for v in row] for row in a], dtype=np.float32)
 
 
 def test_hand_computed_case(oracle):
@@ -110,7 +111,8 @@ def test_properties(seed, n, e, r, F):
     assert np.array_equal(oracle.rspmm_forward(csr2, relation, x), 2 * oracle.rspmm_forward(csr, relation, x))
     # empty rows carry the identity
     empty = np.diff(csr.row_ptr) == 0
-    assert (oracle.rspmm_forward(csr, relation, x, "max")[empty] == -np.inf).all()
+    assert (oracle.rspmm_forward(csr, relation, x, "max")[empty] == np.finfo(np.float32).min).all()
+    assert (oracle.rspmm_forward(csr, relation, x, "min")[empty] == np.finfo(np.float32).max).all()
     assert (oracle.rspmm_forward(csr, relation, x, "add")[empty] == 0).all()
 
 

@@ -51,6 +51,7 @@ EXPORTS = (
     "ultra_rspmm_workspace_bytes",
     "ultra_rspmm_forward_f32",
     "ultra_rspmm_forward_boundary_f32",
+    "ultra_rspmm_frontier_f32",
     "ultra_rspmm_backward_f32",
     "ultra_rspmm_backward_weight_f32",
     "ultra_combine_forward_f32",
@@ -61,6 +62,9 @@ EXPORTS = (
     "ultra_score_forward_f32",
     "ultra_relation_project_f32",
     "ultra_filtered_rank",
+    "ultra_filtered_rank_keys",
+    "ultra_strict_negative",
+    "ultra_edge_removal_weights",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
     "ultra_relcsr_plan_temp_bytes",
@@ -117,6 +121,8 @@ def load():
     lib.ultra_rspmm_forward_f32.argtypes = [seg, vp, vp, vp, vp, vp, sz, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_forward_boundary_f32.restype = i32
     lib.ultra_rspmm_forward_boundary_f32.argtypes = [seg, vp, vp, vp, vp, i64, vp, vp, sz, i64, i64, i64, i32, i32, vp]
+    lib.ultra_rspmm_frontier_f32.restype = i32
+    lib.ultra_rspmm_frontier_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp]
     lib.ultra_rspmm_backward_f32.restype = i32
     lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_weight_f32.restype = i32
@@ -137,6 +143,12 @@ def load():
     lib.ultra_relation_project_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]
     lib.ultra_filtered_rank.restype = i32
     lib.ultra_filtered_rank.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.ultra_filtered_rank_keys.restype = i32
+    lib.ultra_filtered_rank_keys.argtypes = [vp, i64, i64, i64, vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, vp]
+    lib.ultra_strict_negative.restype = i32
+    lib.ultra_strict_negative.argtypes = [vp, i64, vp, vp, i64, i64, i64, vp, i64, vp, vp]
+    lib.ultra_edge_removal_weights.restype = i32
+    lib.ultra_edge_removal_weights.argtypes = [seg, seg, seg, vp, vp, vp, i64, i64, vp, vp, vp, i64, vp]
     lib.ultra_relcsr_coalesce_temp_bytes.restype = sz
     lib.ultra_relcsr_coalesce_temp_bytes.argtypes = [i64]
     lib.ultra_relcsr_coalesce.restype = i32

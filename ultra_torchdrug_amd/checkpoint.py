@@ -7,6 +7,7 @@ of this package uses the same parameter names (``model.layers.{i}.linear.weight`
 load unchanged.  Graph objects that an older checkpoint may still carry are dropped exactly as ``safe_load`` does.
 """
 import os
+import pickle
 
 import torch
 
@@ -18,11 +19,57 @@ GRAPH_KEYS = ("fact_graph", "train_graph", "valid_graph", "test_graph", "train_r
 _REASONER_MARKS = ("relation.weight", "relation_projection", "relation_linear", "query.weight")
 
 
+class _Placeholder:
+    """Stands in for a pickled object of a package that is not installed (torchdrug ``Graph`` / ``PackedGraph``
+    buffers of an un-cleaned checkpoint); such entries are dropped right after loading."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __setstate__(self, state):
+        pass
+
+
+class _TensorsOnlyUnpickler(pickle.Unpickler):
+    """Resolves torch / numpy / builtin container globals only; every ``torchdrug.*`` global becomes a placeholder
+    and anything else is refused -- a checkpoint is data, not code."""
+    _ALLOWED_ROOTS = ("torch", "numpy", "collections", "builtins", "_codecs")
+
+    def find_class(self, module, name):
+        root = module.split(".")[0]
+        if root == "torchdrug":
+            return _Placeholder
+        if root not in self._ALLOWED_ROOTS or (root == "builtins" and name in ("eval", "exec", "compile", "open",
+                                                                               "__import__", "getattr", "setattr")):
+            raise pickle.UnpicklingError("checkpoint refers to %s.%s, which a tensors-only checkpoint never needs"
+                                         % (module, name))
+        return super().find_class(module, name)
+
+
+class _tensors_only_pickle:
+    """``pickle_module`` for ``torch.load``: same interface as ``pickle`` with the restricted unpickler."""
+    __name__ = "pickle"
+    Unpickler = _TensorsOnlyUnpickler
+    load = staticmethod(lambda f, **kw: _TensorsOnlyUnpickler(f, **kw).load())
+
+
+def read_checkpoint(path, map_location=None):
+    """``torch.load`` of a reference checkpoint without executing what it pickles: first as tensors only
+    (``weights_only=True``: what ``util.clean_save`` writes, ``ultra/util.py:278-325``); a file that still carries
+    torchdrug graph objects (``util.py:241-247`` drops them AFTER unpickling, which needs torchdrug installed) is
+    re-read with an unpickler that maps ``torchdrug.*`` classes to placeholders and refuses every other foreign
+    global.  Only load checkpoints from a source you trust either way."""
+    path = os.path.expanduser(path)
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError, ModuleNotFoundError):
+        return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_tensors_only_pickle)
+
+
 def load_checkpoint(task, checkpoint, fix_reasoner=False, optimizer=None, map_location=None):
     """``util.safe_load``: returns the ``(missing_keys, unexpected_keys)`` of the non-strict load."""
     if isinstance(checkpoint, (str, os.PathLike)):
-        state = torch.load(os.path.expanduser(checkpoint), map_location=map_location or task.device,
-                           weights_only=False)
+        state = read_checkpoint(checkpoint, map_location=map_location or task.device)
     else:
         state = checkpoint
     model_state = dict(state["model"])

@@ -24,6 +24,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 
 #include "ultra_rspmm.h"
 
@@ -91,9 +92,11 @@ struct FixParams {
 
 template <int SUM>
 __device__ __forceinline__ float identity() {
+    // min / max start from the largest / lowest FINITE float, as torchdrug's NaryMin / NaryMax do
+    // (std::numeric_limits<scalar_t>::max() / lowest()), so an empty row never feeds an infinity to the layers after it
     if constexpr (SUM == ULTRA_SUM_ADD) return 0.0f;
-    else if constexpr (SUM == ULTRA_SUM_MIN) return __builtin_inff();
-    else return -__builtin_inff();
+    else if constexpr (SUM == ULTRA_SUM_MIN) return 3.402823466e+38f;
+    else return -3.402823466e+38f;
 }
 
 template <int SUM>
@@ -595,6 +598,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(const FixParams p) {
 }
 
 #include "quad.inc"
+#include "frontier.inc"
 
 // d_weight[e] = sum_f (grad[dst,f] * dmask) * (relation[rel,f] MUL input[src,f]); one wave per edge.
 template <int SUM, int MUL, bool UNIT_W>
@@ -879,20 +883,49 @@ int gcd_int(int a, int b) {
     return a;
 }
 
-template <int KIND, int SUM, int MUL, bool UNIT_W, bool REL_LDS>
-int launch_instance(const KParams &p, int grid, size_t lds, hipStream_t stream) {
-    auto kern = segment_kernel<KIND, SUM, MUL, UNIT_W, REL_LDS>;
-    static bool attr_set[16] = {false};
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of ONE kernel function.  Every packed_kernel / quad_kernel
+// instance has the same pointer type void (*)(PParams), so a function-local static would be shared by all of them:
+// the "already set" table is keyed on the kernel's address (per device).
+struct LdsAttrTable {
+    static constexpr int kSlots = 512;
+    const void *kern[kSlots];
+    int dev[kSlots];
+    int n = 0;
+    bool seen(const void *k, int d) const {
+        for (int i = 0; i < n; ++i)
+            if (kern[i] == k && dev[i] == d) return true;
+        return false;
+    }
+    void add(const void *k, int d) {
+        if (n < kSlots) { kern[n] = k; dev[n] = d; ++n; }     // table full: the attribute is simply set again next time
+    }
+};
+LdsAttrTable g_lds_attr;
+std::mutex g_lds_attr_mutex;
+
+int ensure_lds_attribute(const void *kern, size_t lds) {
+    if (lds <= 48 * 1024) return ULTRA_OK;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (lds > 48 * 1024 && dev >= 0 && dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    kMaxLdsBytes));
-        attr_set[dev] = true;
-    }
+    std::lock_guard<std::mutex> lock(g_lds_attr_mutex);
+    if (g_lds_attr.seen(kern, dev)) return ULTRA_OK;
+    HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+    g_lds_attr.add(kern, dev);
+    return ULTRA_OK;
+}
+
+template <typename Kern, typename Params>
+int launch_with_lds(Kern kern, const Params &p, int grid, size_t lds, hipStream_t stream) {
+    const int rc = ensure_lds_attribute(reinterpret_cast<const void *>(kern), lds);
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, p);
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
+}
+
+template <int KIND, int SUM, int MUL, bool UNIT_W, bool REL_LDS>
+int launch_instance(const KParams &p, int grid, size_t lds, hipStream_t stream) {
+    return launch_with_lds(segment_kernel<KIND, SUM, MUL, UNIT_W, REL_LDS>, p, grid, lds, stream);
 }
 
 template <int KIND, int SUM, int MUL>
@@ -933,21 +966,6 @@ int check_segments(const ultra_segments *s) {
     if (s->n_edges > 0 && (s->row == nullptr || s->node_a == nullptr || s->rel == nullptr)) return ULTRA_ERR_NULL_POINTER;
     if (s->n_chunks > 0 && s->chunks == nullptr) return ULTRA_ERR_NULL_POINTER;
     if (s->n_long_rows > 0 && s->long_rows == nullptr) return ULTRA_ERR_NULL_POINTER;
-    return ULTRA_OK;
-}
-
-template <typename Kern, typename Params>
-int launch_with_lds(Kern kern, const Params &p, int grid, size_t lds, hipStream_t stream) {
-    static bool attr_set[16] = {false};   // one table per kernel instantiation
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (lds > 48 * 1024 && dev >= 0 && dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    kMaxLdsBytes));
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, p);
-    HIP_TRY(hipGetLastError());
     return ULTRA_OK;
 }
 
@@ -1297,6 +1315,40 @@ int ultra_rspmm_forward_boundary_f32(const ultra_segments *fwd, const float *rel
                               static_cast<hipStream_t>(stream));
 }
 
+int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_ptr, const int32_t *fwd_rank,
+                             const float *relation, const int32_t *boundary_node, const float *boundary_value,
+                             int64_t block, float *out, int64_t n_dst, int64_t n_rel, int64_t F, void *stream) {
+    int rc = check_segments(by_src);
+    if (rc) return rc;
+    if (src_ptr == nullptr || boundary_node == nullptr || boundary_value == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (by_src->n_edges > 0 && (fwd_rank == nullptr || relation == nullptr)) return ULTRA_ERR_NULL_POINTER;
+    if (block != 64 || F <= 0 || F % 64 != 0 || n_dst < 0 || n_rel < 0 || by_src->piece_len <= 0) return ULTRA_ERR_BAD_SHAPE;
+    if (n_dst == 0) return ULTRA_OK;
+    if (out == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(relation) |
+         reinterpret_cast<uintptr_t>(boundary_value)) & 15u) return ULTRA_ERR_BAD_SHAPE;      // 16-byte row segments
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_dst * (size_t)F * sizeof(float), s));
+    FrontierParams p;
+    p.src_ptr = src_ptr;
+    p.dst = by_src->node_a;
+    p.rel = by_src->rel;
+    p.weight = by_src->weight;
+    p.fwd_rank = fwd_rank;
+    p.relation = relation;
+    p.bnode = boundary_node;
+    p.bvec = boundary_value;
+    p.out = out;
+    p.F = F;
+    p.piece_len = (int)by_src->piece_len;
+    p.slices = 4;
+    const dim3 grid((unsigned)(F / 64), (unsigned)p.slices);
+    if (by_src->weight == nullptr) hipLaunchKernelGGL(frontier_kernel<true>, grid, dim3(kFrontierThreads), 0, s, p);
+    else hipLaunchKernelGGL(frontier_kernel<false>, grid, dim3(kFrontierThreads), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
 int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments *by_rel, const float *relation,
                              const float *input, const float *output, const float *output_grad, float *d_input,
                              float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_dst,
@@ -1414,3 +1466,4 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
 
 #include "combine_train.inc"
 #include "dense.inc"
+#include "sampler.inc"

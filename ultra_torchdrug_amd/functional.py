@@ -25,6 +25,11 @@ _sparse_cache = collections.OrderedDict()
 _SPARSE_CACHE_ENTRIES = 4
 
 
+def accepts(tensor):
+    """Backend interface (``backend.py``): the HIP library computes on device tensors only."""
+    return bool(tensor.is_cuda)
+
+
 def _ops(sum, mul):
     if sum not in _lib.SUM_OPS:
         raise ValueError("Can't find a rspmm operator for sum=`%s` (expected add, min or max)" % sum)
@@ -124,6 +129,41 @@ def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, bou
             seg.pointer, relation.data_ptr(), input.data_ptr(), add_rows.data_ptr() if add_rows is not None else None,
             out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, csr.shape[1], csr.shape[2], F, sum_op,
             mul_op, _stream()))
+    return out
+
+
+def frontier_supported(sum, mul, F):
+    """The first-layer shortcut holds where a zero source row contributes exactly +-0: summed DistMult messages."""
+    return sum == "add" and mul == "mul" and F % 64 == 0
+
+
+def rspmm_frontier(csr, relation, boundary):
+    """``rspmm_forward(csr, relation, <dense boundary>, "add", "mul", boundary=boundary)`` for the FIRST Bellman-Ford
+    layer, whose input is the boundary itself (``ultra/model.py:116-120``): zero outside row ``node[b]`` of query block
+    ``b``.  Visits only the out-edges of the boundary nodes; same bits as the full kernels (see ``csrc/frontier.inc``).
+    ``boundary = (node int32 (B,), value fp32 (B, 64))``; forward only."""
+    b_node, b_value = boundary
+    b_value = b_value.contiguous()
+    n_dst, n_src, n_rel = csr.shape
+    F = b_value.numel()
+    if relation.dim() != 2 or relation.shape != (n_rel, F) or relation.dtype != torch.float32 or not relation.is_cuda:
+        raise RuntimeError("rspmm_frontier: relation must be fp32 (%d, %d) on the HIP device" % (n_rel, F))
+    if (b_node.dtype != torch.int32 or b_node.dim() != 1 or b_value.dtype != torch.float32 or b_value.dim() != 2
+            or b_value.shape != (b_node.shape[0], 64) or not b_node.is_contiguous()
+            or b_node.device != relation.device or b_value.device != relation.device or csr.device != relation.device):
+        raise RuntimeError("rspmm_frontier: boundary must be (int32 (B,), fp32 (B, 64)) on %s" % relation.device)
+    if n_dst != n_src:
+        raise RuntimeError("rspmm_frontier: the boundary rows index the source nodes of a square adjacency")
+    relation = relation.contiguous()
+    out = torch.empty(n_dst, F, dtype=torch.float32, device=relation.device)
+    if out.numel() == 0:
+        return out
+    src_ptr, fwd_rank = csr.frontier_index
+    lib = _lib.load()
+    with torch.cuda.device(relation.device):
+        _lib.check(lib.ultra_rspmm_frontier_f32(
+            csr.by_src.pointer, src_ptr.data_ptr(), fwd_rank.data_ptr(), relation.data_ptr(), b_node.data_ptr(),
+            b_value.data_ptr(), 64, out.data_ptr(), n_dst, n_rel, F, _stream()))
     return out
 
 
@@ -289,6 +329,64 @@ def filtered_rank(pred, target, filt_ptr=None, filt_node=None):
             filt_ptr.data_ptr() if filt_ptr is not None else None,
             filt_node.data_ptr() if filt_ptr is not None else None, rank.data_ptr(), _stream()))
     return rank
+
+
+def remove_triples(graph, h, t, r, n_base_rel):
+    """``graph`` (with inverse edges) minus the edges ``(h, t, r)`` / ``(t, h, r + n_base_rel)``, as zero weights on its
+    cached plans: ``remove_easy_edges`` (``ultra/model.py:57-74``) for summed messages, natively and capturable."""
+    return graph.without_triples(h, t, r, n_base_rel)
+
+
+def filtered_rank_keys(pred, target, keys, anchor, rel, n_rel):
+    """Filtered ranks of one prediction side without filter lists or masks: ``pred`` fp32 ``(B, N)`` (a strided view of
+    the ``(B, 2, N)`` scores is fine), ``target`` / ``anchor`` / ``rel`` int64 ``(B,)``; ``keys``: the graph's sorted
+    distinct completion keys of that side (``Graph.completion_keys``) or ``None`` for the unfiltered rank.  Returns
+    int64 ``(B,)``.  No host synchronisation (capturable)."""
+    rows, n_cand = pred.shape
+    if pred.dtype != torch.float32 or pred.stride(1) != 1 or not pred.is_cuda:
+        raise RuntimeError("filtered_rank_keys: pred must be fp32 (B, N) with contiguous rows on the HIP device")
+    for name, t in (("target", target), ("anchor", anchor), ("rel", rel)):
+        if t.dtype != torch.int64 or t.shape != (rows,) or t.device != pred.device:
+            raise RuntimeError("filtered_rank_keys: %s must be int64 (%d,) on %s" % (name, rows, pred.device))
+    if keys is not None and (keys.dtype != torch.int64 or keys.dim() != 1 or not keys.is_contiguous()
+                             or keys.device != pred.device):
+        raise RuntimeError("filtered_rank_keys: keys must be a contiguous int64 vector on %s" % pred.device)
+    rank = torch.empty(rows, dtype=torch.int64, device=pred.device)
+    if rows == 0:
+        return rank
+    anchor, rel = anchor.contiguous(), rel.contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(pred.device):
+        _lib.check(lib.ultra_filtered_rank_keys(
+            pred.data_ptr(), rows, n_cand, pred.stride(0), target.data_ptr(), target.stride(0),
+            keys.data_ptr() if keys is not None else None, keys.numel() if keys is not None else 0, anchor.data_ptr(),
+            rel.data_ptr(), 1, int(n_rel), rank.data_ptr(), 1, _stream()))
+    return rank
+
+
+def strict_negatives(keys, anchor, rel, n_rel, n_node, rand):
+    """Strict negative sampling (``ultra/task.py:102-118``) from the graph's sorted completion keys: for every row
+    ``q`` and uniform number ``rand[q, s]`` the ``floor(rand * n_free)``-th entity that does NOT complete
+    ``(anchor[q], rel[q], ?)`` -- the entity ``variadic_sample(mask.nonzero()[:, 1], mask.sum(-1), S)`` returns for the
+    same numbers, with no ``(B, N)`` mask and no host synchronisation.  Returns int64 ``(B, S)``."""
+    rows, n_sample = rand.shape
+    if rand.dtype != torch.float32 or not rand.is_cuda or not rand.is_contiguous():
+        raise RuntimeError("strict_negatives: rand must be contiguous fp32 (B, S) on the HIP device")
+    anchor, rel = anchor.contiguous(), rel.contiguous()
+    for name, t in (("anchor", anchor), ("rel", rel)):
+        if t.dtype != torch.int64 or t.shape != (rows,) or t.device != rand.device:
+            raise RuntimeError("strict_negatives: %s must be int64 (%d,) on %s" % (name, rows, rand.device))
+    if keys.dtype != torch.int64 or keys.dim() != 1 or not keys.is_contiguous() or keys.device != rand.device:
+        raise RuntimeError("strict_negatives: keys must be a contiguous int64 vector on %s" % rand.device)
+    out = torch.empty(rows, n_sample, dtype=torch.int64, device=rand.device)
+    if out.numel() == 0:
+        return out
+    lib = _lib.load()
+    with torch.cuda.device(rand.device):
+        _lib.check(lib.ultra_strict_negative(keys.data_ptr(), keys.numel(), anchor.data_ptr(), rel.data_ptr(), rows,
+                                             int(n_rel), int(n_node), rand.data_ptr(), n_sample, out.data_ptr(),
+                                             _stream()))
+    return out
 
 
 class _CombineFunction(torch.autograd.Function):

@@ -38,6 +38,7 @@ class Graph:
         self._relcsr = None
         self._adjacency = None
         self._match_index = None
+        self._completion = None
         for k, v in attributes.items():
             setattr(self, k, v)
 
@@ -124,6 +125,38 @@ class Graph:
         if self.edge_list.shape[1] == 3:
             g._relcsr = self.relcsr.with_edge_weights(edge_weight)
         return g
+
+    def without_triples(self, h, t, r, n_base_rel):
+        """This graph (one WITH inverse edges, ``undirected(add_inverse=True)``) minus the edges ``(h, t, r)`` and
+        their inverses ``(t, h, r + n_base_rel)``, as zero weights on the shared plans (``RelCSR.with_removed_edges``):
+        what ``remove_easy_edges`` + ``undirected`` give (``ultra/model.py:57-74,166``) for summed messages, without a
+        new edge list, a re-sort or a host synchronisation.  Only ``relcsr`` of the result reflects the removal."""
+        g = Graph.__new__(Graph)
+        g.edge_list, g.edge_weight = self.edge_list, self.edge_weight
+        g.num_node, g.num_relation = self.num_node, self.num_relation
+        g.requires_grad, g._adjacency, g._match_index = False, None, self._match_index
+        g._completion = getattr(self, "_completion", None)
+        g._relcsr = self.relcsr.with_removed_edges(h, t, r, n_base_rel)
+        return g
+
+    def completion_keys(self, anchor_col):
+        """Sorted DISTINCT int64 keys ``(anchor * num_relation + relation) * num_node + other`` of the triples, with
+        ``anchor`` = column ``anchor_col`` of ``edge_list`` (0: head, answers "which tails complete (h, r, ?)"; 1: tail)
+        and ``other`` the opposite column.  Built once per graph; the device-side filter / negative-sampling kernels
+        binary-search it (``csrc/sampler.inc``) where the reference builds ``(B, N)`` masks (``ultra/task.py:65-100``)."""
+        cache = getattr(self, "_completion", None)
+        if cache is None:
+            cache = self._completion = {}
+        if anchor_col not in cache:
+            if self.edge_list.shape[1] != 3:
+                raise ValueError("completion_keys needs a relational graph")
+            n_rel = max(self.num_relation, 1)
+            if float(self.num_node) ** 2 * n_rel >= 2.0 ** 63:
+                raise ValueError("graph too large for 64-bit completion keys")
+            anchor, other = self.edge_list[:, anchor_col], self.edge_list[:, 1 - anchor_col]
+            key = (anchor * n_rel + self.edge_list[:, 2]) * self.num_node + other
+            cache[anchor_col] = torch.unique(key)          # sorted, distinct
+        return cache[anchor_col]
 
     def edge_mask(self, index):
         """Keep the edges selected by a bool mask or an index tensor; nodes are kept."""

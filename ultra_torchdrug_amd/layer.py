@@ -15,7 +15,12 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import functional
+from . import backend
+
+# First-layer shortcut (csrc/frontier.inc): the first layer of a Bellman-Ford aggregates from the boundary, which is zero
+# outside one row per query; with summed DistMult messages only the out-edges of those rows are visited.  Same bits as
+# the full kernel; the switch exists so that bench.py can report the step with and without it.
+FRONTIER_FIRST_LAYER = True
 
 
 class MLP(nn.Module):
@@ -34,13 +39,13 @@ class MLP(nn.Module):
     def _library_linear(self, layer, x, relu):
         """Inference on the GPU: the layer runs in libultra_rspmm's documented summation order (bit-identical to the
         CPU oracle); training and unsupported shapes keep nn.Linear."""
-        on_device = x.is_cuda or getattr(functional, "cpu_ok", False)
-        if not (on_device and hasattr(functional, "linear_forward") and x.dtype == torch.float32
-                and layer.bias is not None and functional.linear_supported(layer.in_features, layer.out_features)):
+        ops = backend.get()
+        if not (ops.accepts(x) and x.dtype == torch.float32 and layer.bias is not None
+                and ops.linear_supported(layer.in_features, layer.out_features)):
             return None
         if torch.is_grad_enabled() and (x.requires_grad or layer.weight.requires_grad):
             return None
-        return functional.linear_forward(x, layer.weight, layer.bias, relu=relu)
+        return ops.linear_forward(x, layer.weight, layer.bias, relu=relu)
 
     def forward(self, input):
         layer_input = input
@@ -80,14 +85,15 @@ class _RelationalConvBase(nn.Module):
     def _relation_table(self, graph, batch_size):
         raise NotImplementedError
 
-    def forward(self, graph, input, shortcut=False):
+    def forward(self, graph, input, shortcut=False, input_is_boundary=False):
         """``MessagePassingBase.forward``: ``combine(input, message_and_aggregate(graph, input))``.  ``shortcut``
         additionally adds ``input`` (the caller's ``hidden + layer_input``, ``ultra/model.py:126-127``) so that the
-        inference path can run combine + shortcut as ONE HIP kernel."""
-        update = self.message_and_aggregate(graph, input)
+        inference path can run combine + shortcut as ONE HIP kernel.  ``input_is_boundary``: the caller's promise that
+        ``input`` is ``graph.boundary`` (the first layer of a Bellman-Ford, ``ultra/model.py:116-120``)."""
+        update = self.message_and_aggregate(graph, input, input_is_boundary=input_is_boundary)
         if self._fusable(input, update):
             ln = self.layer_norm
-            return functional.combine(input, update, self.linear.weight, self.linear.bias,
+            return backend.get().combine(input, update, self.linear.weight, self.linear.bias,
                                       ln.weight if ln else None, ln.bias if ln else None,
                                       ln.eps if ln else 1e-5, relu=self.activation is F.relu, shortcut=shortcut,
                                       reuse_update=True)       # `update` is this call's own temporary
@@ -101,12 +107,10 @@ class _RelationalConvBase(nn.Module):
         """The fused epilogue kernels (forward and backward) cover the shipped layer shape: 64 -> 64, concat of 2,
         relu or no activation; anything else runs the reference's ATen ops."""
         ln = self.layer_norm
-        on_device = input.is_cuda or getattr(functional, "cpu_ok", False)   # cpu_ok: only the tests' oracle stand-in
-        return (on_device and input.dtype == torch.float32 and input.shape == update.shape
+        return (backend.get().accepts(input) and input.dtype == torch.float32 and input.shape == update.shape
                 and input.shape[-1] == 64 and self.output_dim == 64 and tuple(self.linear.weight.shape) == (64, 128)
                 and (self.activation is F.relu or not self.activation)
-                and (ln is None or (ln.elementwise_affine and ln.bias is not None))
-                and hasattr(functional, "combine"))
+                and (ln is None or (ln.elementwise_affine and ln.bias is not None)))
 
     # ---- O(E) definition, used for rotate / graphs that require grad (layer.py:52-109, :232-296) ---------
     def message(self, graph, input):
@@ -162,7 +166,7 @@ class _RelationalConvBase(nn.Module):
         return (features.unsqueeze(-1) * scales.unsqueeze(-2)).flatten(-2)
 
     # ---- rspmm path (layer.py:111-182, :298-384) -------------------------------------------------------
-    def message_and_aggregate(self, graph, input):
+    def message_and_aggregate(self, graph, input, input_is_boundary=False):
         if graph.requires_grad or self.message_func == "rotate":
             return self.aggregate(graph, self.message(graph, input))
         if self.message_func not in self.message2mul:
@@ -181,7 +185,8 @@ class _RelationalConvBase(nn.Module):
         func = self.aggregate_func
         bound = not func.endswith("_nobound")
         kind = func[:-len("_nobound")] if not bound else func
-        rspmm = functional.generalized_rspmm
+        ops = backend.get()
+        rspmm = ops.generalized_rspmm
 
         if kind not in ("sum", "mean", "max", "pna"):
             raise ValueError("Unknown aggregation function `%s`" % self.aggregate_func)
@@ -189,21 +194,23 @@ class _RelationalConvBase(nn.Module):
         if kind in ("mean", "pna"):
             degree_out = graph.degree_out.unsqueeze(-1) + 1
         # inference: `update + boundary` / `max(update, boundary)` ride along in the rspmm kernel (bit-identical)
-        fuse_bound = (bound and input.is_cuda and hasattr(functional, "rspmm_forward")
-                      and self._no_grad(input, relation_input, boundary))
+        fuse_bound = bound and ops.accepts(input) and self._no_grad(input, relation_input, boundary)
         # the boundary in its sparse form (node per query, value per query), when the caller attached it
         sparse_bound = getattr(graph, "boundary_sparse", None) if fuse_bound else None
         bound_args = dict(add_rows=boundary) if sparse_bound is None else dict(boundary=sparse_bound)
         if kind in ("sum", "mean"):
-            if fuse_bound:
-                update = functional.rspmm_forward(adjacency, relation_input, input, "add", mul, **bound_args)
-            elif bound and input.is_cuda and hasattr(functional, "rspmm_sum_plus"):      # training
+            if (fuse_bound and input_is_boundary and sparse_bound is not None and FRONTIER_FIRST_LAYER
+                    and ops.frontier_supported("add", mul, input.shape[1]) and sparse_bound[1].shape[-1] == 64):
+                # first layer: only the out-edges of the boundary rows carry non-zero messages (csrc/frontier.inc)
+                update = ops.rspmm_frontier(adjacency, relation_input, sparse_bound)
+            elif fuse_bound:
+                update = ops.rspmm_forward(adjacency, relation_input, input, "add", mul, **bound_args)
+            elif bound and ops.accepts(input):      # training
                 sparse_train = getattr(graph, "boundary_sparse", None)
                 if sparse_train is not None:
-                    update = functional.rspmm_sum_plus(adjacency, relation_input, input, None, mul=mul,
-                                                       boundary=sparse_train)
+                    update = ops.rspmm_sum_plus(adjacency, relation_input, input, None, mul=mul, boundary=sparse_train)
                 else:
-                    update = functional.rspmm_sum_plus(adjacency, relation_input, input, boundary, mul=mul)
+                    update = ops.rspmm_sum_plus(adjacency, relation_input, input, boundary, mul=mul)
             else:
                 update = rspmm(adjacency, relation_input, input, sum="add", mul=mul)
                 if bound:
@@ -212,7 +219,7 @@ class _RelationalConvBase(nn.Module):
                 update = update / degree_out
         elif kind == "max":
             if fuse_bound:
-                update = functional.rspmm_forward(adjacency, relation_input, input, "max", mul, **bound_args)
+                update = ops.rspmm_forward(adjacency, relation_input, input, "max", mul, **bound_args)
             else:
                 update = rspmm(adjacency, relation_input, input, sum="max", mul=mul)
                 if bound:

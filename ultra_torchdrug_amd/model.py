@@ -9,7 +9,7 @@ from collections.abc import Sequence
 import torch
 from torch import nn
 
-from . import layer
+from . import backend, layer
 from .graph import Graph
 
 
@@ -72,11 +72,12 @@ class TransferNBFNet(nn.Module):
         """model.py:57-74: a new graph without the batch's positive edges."""
         return graph.edge_mask(self.easy_edge_mask(graph, h_index, t_index, r_index))
 
-    def _removal_by_zero_weight(self):
+    def _removal_by_zero_weight(self, sums_only=False):
         """Dropping an edge == giving it weight 0 exactly when messages are summed (0 * m adds +0.0); for min/max a
-        zero message is not "no message", and rotate / PNA's degree scaling read the edge list itself."""
-        return all(conv.aggregate_func in ("sum", "sum_nobound", "mean", "mean_nobound")
-                   and conv.message_func in conv.message2mul for conv in self.layers)
+        zero message is not "no message", and rotate / PNA's degree scaling read the edge list itself.  ``sums_only``:
+        not even ``mean`` (its degree is read from ``graph.edge_weight``, which the native removal leaves alone)."""
+        ok = ("sum", "sum_nobound") if sums_only else ("sum", "sum_nobound", "mean", "mean_nobound")
+        return all(conv.aggregate_func in ok and conv.message_func in conv.message2mul for conv in self.layers)
 
     def negative_sample_to_tail(self, h_index, t_index, r_index, num_relations):
         """model.py:76-83: rows that corrupt heads become tail queries of the inverse relation."""
@@ -125,7 +126,8 @@ class TransferNBFNet(nn.Module):
                 step_graph.requires_grad = True
             # the shortcut `hidden + layer_input` (model.py:126-127) is applied inside the layer call
             hidden = conv(step_graph, layer_input,
-                          shortcut=self.short_cut and conv.output_dim == layer_input.shape[-1])
+                          shortcut=self.short_cut and conv.output_dim == layer_input.shape[-1],
+                          input_is_boundary=layer_input is boundary)
             hiddens.append(hidden)
             step_graphs.append(step_graph)
             layer_input = hidden
@@ -143,12 +145,12 @@ class TransferNBFNet(nn.Module):
         """Inference on the GPU with per-query relation representations and the shipped 64 -> 64 -> 64 projections:
         the ``(R, B * D)`` relation tables of ALL layers from one launch (each layer otherwise issues two linear
         launches and a transposing copy of its own, layer.py:318-326).  ``None``: every layer builds its own."""
-        F_ = layer.functional
+        ops = backend.get()
         convs = list(self.layers)
-        if not hasattr(F_, "relation_project") or torch.is_grad_enabled() or not convs:
+        if torch.is_grad_enabled() or not convs:
             return None
         relation = getattr(convs[0], "relation", None)
-        if relation is None or not relation.is_cuda or relation.dim() != 3 or relation.shape[0] != batch_size \
+        if relation is None or not ops.accepts(relation) or relation.dim() != 3 or relation.shape[0] != batch_size \
                 or relation.shape[-1] != 64 or relation.dtype != torch.float32:
             return None
         weights = []
@@ -160,7 +162,7 @@ class TransferNBFNet(nn.Module):
             if not ok:
                 return None
             weights.append((mlp.layers[0].weight, mlp.layers[0].bias, mlp.layers[1].weight, mlp.layers[1].bias))
-        tables = F_.relation_project(relation, weights)
+        tables = ops.relation_project(relation, weights)
         return {id(conv): table for conv, table in zip(convs, tables)}
 
     def score_all_entities(self, graph, rel_query_list, h_index, r_index):
@@ -177,22 +179,27 @@ class TransferNBFNet(nn.Module):
         graph = self._undirected(graph)
         parts = self.bellmanford(graph, h_index, r_index, want_feature=False)
         first, second = self.mlp.layers
-        return layer.functional.score_all_entities(parts["hidden"], parts["query"], first.weight, first.bias,
-                                                   second.weight, second.bias)
+        return backend.get().score_all_entities(parts["hidden"], parts["query"], first.weight, first.bias,
+                                                 second.weight, second.bias)
 
     def forward(self, graph, rel_query_list, h_index, t_index, r_index=None, all_loss=None, metric=None,
                 all_entities=False):
         """model.py:145-194: scores of shape ``h_index.shape``.  ``all_entities=True`` is the caller's promise that
         every row of the corrupted side lists ALL entities in order (full-batch evaluation, task.py:249-259); the
         tail gather is then the identity and the score head runs as one fused kernel."""
-        keep = None
+        keep, removal = None, None
         if all_loss is not None:
             # training: the batch's own positive edges must not carry messages (model.py:146-147).  The reference
             # builds (and torchdrug re-sorts) a new graph every step; here the cached plans of the full graph are
             # reused and the removed edges get weight 0 for this step -- identical sums, no sort.
-            keep = self.easy_edge_mask(graph, h_index, t_index, r_index)
-            if not (graph.num_relation and self._removal_by_zero_weight()):
-                graph, keep = graph.edge_mask(keep), None
+            if (graph.num_relation and r_index is not None and not self.remove_one_hop
+                    and self._removal_by_zero_weight(sums_only=True) and getattr(self, "_static_keep", None) is None):
+                # one native call on the graph with inverse edges (below): no match(), no host synchronisation
+                removal = (h_index, t_index, r_index)
+            else:
+                keep = self.easy_edge_mask(graph, h_index, t_index, r_index)
+                if not (graph.num_relation and self._removal_by_zero_weight()):
+                    graph, keep = graph.edge_mask(keep), None
 
         self.query = rel_query_list[0]
         if len(rel_query_list) > 1:
@@ -212,6 +219,8 @@ class TransferNBFNet(nn.Module):
             graph = self._undirected(graph)
             if keep is not None:        # undirected() interleaves every edge with its inverse
                 graph = graph.reweighted(graph.edge_weight * keep.repeat_interleave(2))
+            if removal is not None:
+                graph = backend.get().remove_triples(graph, *removal, num_relations)
             h_index, t_index, r_index = self.negative_sample_to_tail(h_index, t_index, r_index, num_relations)
         else:
             graph = self.as_relational_graph(graph)
@@ -225,8 +234,8 @@ class TransferNBFNet(nn.Module):
         if all_entities and self._fused_score_ok(graph, t_index, metric):
             parts = self.bellmanford(graph, h_index[:, 0], r_index[:, 0], want_feature=False)
             first, second = self.mlp.layers
-            score = layer.functional.score_all_entities(parts["hidden"], parts["query"], first.weight, first.bias,
-                                                        second.weight, second.bias)
+            score = backend.get().score_all_entities(parts["hidden"], parts["query"], first.weight, first.bias,
+                                                     second.weight, second.bias)
             return score.view(shape)
         output = self.bellmanford(graph, h_index[:, 0], r_index[:, 0])
         feature = output["node_feature"].transpose(0, 1)
@@ -252,10 +261,8 @@ class TransferNBFNet(nn.Module):
         return self._fused_head_ok(t_index, metric) and t_index.shape[1] == graph.num_node
 
     def _fused_head_ok(self, index, metric):
-        F_ = layer.functional
         mlp = self.mlp
-        dev_ok = index.is_cuda or getattr(F_, "cpu_ok", False)
-        return (dev_ok and hasattr(F_, "score_all_entities") and not torch.is_grad_enabled() and metric is None
+        return (backend.get().accepts(index) and not torch.is_grad_enabled() and metric is None
                 and not self.symmetric and not self.concat_hidden and self.dims[0] == 64 and self.dims[-1] == 64
                 and len(mlp.layers) == 2 and mlp.layers[0].in_features == 128 and mlp.layers[0].out_features == 128
                 and mlp.layers[1].out_features == 1 and mlp.activation is torch.nn.functional.relu

@@ -88,7 +88,8 @@ class CustomNBFNet(nn.Module):
         layer_input = boundary
         for conv in self.layers:
             # shortcut (rel_model.py:371-372) applied inside the layer call
-            hidden = conv(graph, layer_input, shortcut=self.short_cut and conv.output_dim == layer_input.shape[-1])
+            hidden = conv(graph, layer_input, shortcut=self.short_cut and conv.output_dim == layer_input.shape[-1],
+                          input_is_boundary=layer_input is boundary)
             layer_input = hidden
         return layer_input
 

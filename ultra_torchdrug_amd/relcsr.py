@@ -200,6 +200,15 @@ class Segments:
         other._refresh_struct()
         return other
 
+    def with_weight_buffer(self, buffer):
+        """As :meth:`reweighted`, for a weight array that already carries its ``PACK_SLACK`` trailing ones."""
+        import copy
+        other = copy.copy(self)
+        other.weight = buffer
+        other.struct = _lib.UltraSegments()
+        other._refresh_struct()
+        return other
+
     @property
     def device(self):
         return self.row.device
@@ -408,6 +417,28 @@ class RelCSR:
                                     self._w(order), n_rel, n_node_a=n_src, n_rel_table=n_rel, **self._opts)
         return self._by_rel
 
+    @property
+    def frontier_index(self):
+        """``(src_ptr, fwd_rank)`` for :func:`functional.rspmm_frontier` (first Bellman-Ford layer): the first out-edge
+        of every source node in ``by_src`` order, and for each of those edges its position inside its destination row
+        in FORWARD order (``rank // piece_len`` = the piece of a split row the edge is summed in).  int32, built once
+        per graph; a reweighted RelCSR shares its base's."""
+        base = getattr(self, "_base", None)
+        if base is not None:
+            return base.frontier_index
+        if getattr(self, "_frontier_index", None) is None:
+            _ = self.by_src                                        # builds the (src, dst, rel) order
+            n_dst, n_src, _n_rel = self.shape
+            dev = self.device
+            fwd_ptr = torch.zeros(n_dst + 1, dtype=torch.long, device=dev)
+            torch.cumsum(torch.bincount(self.dst, minlength=n_dst), 0, out=fwd_ptr[1:])
+            rank_fwd = torch.arange(self.n_edges, device=dev) - fwd_ptr[self.dst]
+            src_ptr = torch.zeros(n_src + 1, dtype=torch.long, device=dev)
+            torch.cumsum(torch.bincount(self.src, minlength=n_src), 0, out=src_ptr[1:])
+            self._frontier_index = (src_ptr.to(torch.int32).contiguous(),
+                                    rank_fwd[self._by_src_order].to(torch.int32).contiguous())
+        return self._frontier_index
+
     def with_edge_weights(self, edge_weight):
         """RelCSR over the same edge set with other weights, given per ORIGINAL (un-coalesced) edge; duplicates of
         one triple add up, as ``coalesce()`` would.  Shares the sorted index arrays and chunk schedules."""
@@ -419,8 +450,39 @@ class RelCSR:
         w = torch.zeros(self.n_edges, dtype=torch.float32, device=self.device)
         w.index_add_(0, self.edge_of_input, edge_weight.to(torch.float32))
         other.weight, other.unit_weight = w, False
-        other._base = self
+        # the object that owns the sorted plans and their permutations: reweighting a reweighted RelCSR goes back to it
+        other._base = getattr(self, "_base", None) or self
         other._fwd = other._by_src = other._by_rel = None
+        return other
+
+    def with_removed_edges(self, h, t, r, n_base_rel):
+        """RelCSR over the same edge set in which the edges ``(h[i] -> t[i], r[i])`` and their inverses
+        ``(t[i] -> h[i], r[i] + n_base_rel)`` carry weight 0 (``remove_easy_edges``, ``ultra/model.py:57-74``, on the
+        graph with inverse edges; triples that are not edges are ignored).  One native call fills the weight arrays of
+        all three plans by binary search in their sorted index arrays: no ``match``, no host synchronisation, static
+        shapes (capturable).  Shares every index array and schedule with this object."""
+        base = getattr(self, "_base", None) or self
+        lib = _lib.load()
+        dev = self.device
+        h, t, r = (x.reshape(-1).contiguous() for x in (h, t, r))
+        E = base.n_edges
+        plans = (self.fwd, self.by_src, self.by_rel)         # their weights are the starting point
+        w = [torch.empty(E + PACK_SLACK, dtype=torch.float32, device=dev) for _ in range(3)]
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_edge_removal_weights(
+                plans[0].pointer, plans[1].pointer, plans[2].pointer, h.data_ptr(), t.data_ptr(), r.data_ptr(),
+                h.numel(), int(n_base_rel), w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(), PACK_SLACK,
+                torch.cuda.current_stream().cuda_stream))
+        other = RelCSR.__new__(RelCSR)
+        other.shape, other._opts = self.shape, self._opts
+        other.chunk_edges, other.piece_len = self.chunk_edges, self.piece_len
+        other.dst, other.src, other.rel_id = self.dst, self.src, self.rel_id
+        other.edge_of_input, other.n_edges = self.edge_of_input, self.n_edges
+        other.weight, other.unit_weight = w[0][:E], False
+        other._base = base
+        other._fwd = plans[0].with_weight_buffer(w[0])
+        other._by_src = plans[1].with_weight_buffer(w[1])
+        other._by_rel = plans[2].with_weight_buffer(w[2])
         return other
 
     def degree_in(self):

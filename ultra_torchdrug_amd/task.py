@@ -18,7 +18,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import layer
+from . import backend, layer
 from .graph import Graph
 
 
@@ -60,6 +60,8 @@ class KnowledgeGraphCompletion(nn.Module):
         self.fuse_sides = True
         self.contexts = {}
         self.split = None
+        if fact_ratio is not None and not 0 < float(fact_ratio) <= 1:
+            raise ValueError("fact_ratio must be in (0, 1], got %r" % (fact_ratio,))
 
     @property
     def device(self):
@@ -72,11 +74,16 @@ class KnowledgeGraphCompletion(nn.Module):
     # sets, shared relation vocabulary); multi-graph pre-training has one per dataset (task.py:655-672).  They are
     # plain attributes, not module buffers, so state_dict() holds exactly the tensors a reference checkpoint holds
     # after util.clean_save.
-    def add_context(self, name, graph, fact_graph=None, fact_mask=None):
+    def add_context(self, name, graph, fact_graph=None, fact_mask=None, train_triples=None):
+        """``train_triples`` (``(T, 3)`` rows of (h, t, r); default: the fact edges): the training set the
+        ``sample_weight`` degree tables are counted over (task.py:50-57)."""
         if fact_graph is None:
             fact_graph = graph if fact_mask is None else graph.edge_mask(fact_mask)
         ctx = {"graph": graph, "fact_graph": fact_graph,
                "rel_graphs": [rel_model.construct_relation_graph(fact_graph) for rel_model in self.rel_models]}
+        if self.sample_weight:
+            ctx["degree"] = self._degree_tables(fact_graph.edge_list if train_triples is None else train_triples,
+                                                fact_graph.num_relation)
         self.contexts[str(name)] = ctx
         if self.split is None:
             self.split = str(name)
@@ -100,12 +107,44 @@ class KnowledgeGraphCompletion(nn.Module):
     num_entity = property(lambda self: self._ctx("fact_graph").num_node)
     num_relation = property(lambda self: self._ctx("fact_graph").num_relation)
 
-    def preprocess(self, graph, fact_mask=None):
+    def preprocess(self, graph, fact_mask=None, generator=None):
         """Transductive setup (task.py:31-63, 215-226): ``graph`` holds all triples (train+valid+test) with (h, t, r)
-        rows; ``fact_mask`` selects the edges message passing may use (train only)."""
+        rows; ``fact_mask`` selects the training edges, which message passing may use.  With ``fact_ratio`` only that
+        fraction of them (a random subset) stays in the fact graph and the REST becomes the training set
+        (task.py:42-47); ``self.train_index`` lists the training triples' rows of ``graph.edge_list`` either way."""
         self.contexts, self.split = {}, None
-        self.add_context("default", graph, fact_mask=fact_mask)
+        if fact_mask is None:
+            fact_mask = torch.ones(graph.num_edge, dtype=torch.bool, device=graph.device)
+        fact_mask = torch.as_tensor(fact_mask, dtype=torch.bool, device=graph.device).clone()
+        train_index = fact_mask.nonzero().flatten()
+        if self.fact_ratio:
+            length = int(len(train_index) * self.fact_ratio)
+            rest = torch.randperm(len(train_index), generator=generator)[length:].to(graph.device)
+            train_index = train_index[rest]
+            fact_mask[train_index] = False
+        self.train_index = train_index
+        self.add_context("default", graph, fact_mask=fact_mask, train_triples=graph.edge_list[train_index])
         return self
+
+    @staticmethod
+    def _degree_tables(triples, num_relation):
+        """task.py:50-57 -- how often each (h, r) and each (t, r) occurs in the training set -- as sorted pair keys
+        with counts (the reference's dense ``(num_entity, num_relation)`` tables do not scale to big graphs)."""
+        h, t, r = triples[:, 0], triples[:, 1], triples[:, 2]
+        n_rel = max(int(num_relation), 1)
+        return {"n_rel": n_rel,
+                "hr": torch.unique(h * n_rel + r, return_counts=True),
+                "tr": torch.unique(t * n_rel + r, return_counts=True)}
+
+    def _pair_degree(self, side, node, rel):
+        table = self._ctx("degree")
+        keys, counts = table[side]
+        keys, counts = keys.to(node.device), counts.to(node.device)
+        want = node * table["n_rel"] + rel
+        if keys.numel() == 0:
+            return torch.zeros_like(want)
+        pos = torch.searchsorted(keys, want).clamp(max=keys.numel() - 1)
+        return torch.where(keys[pos] == want, counts[pos], torch.zeros_like(want))
 
     def preprocess_inductive(self, train_graph, valid_graph, test_graph, graph=None, inductive_graph=None):
         """Inductive setup (task.py:539-581, target :435-450): messages travel on the split's own graph; rankings are
@@ -169,11 +208,25 @@ class KnowledgeGraphCompletion(nn.Module):
 
     @torch.no_grad()
     def _strict_negative(self, pos_h_index, pos_t_index, pos_r_index):
-        """task.py:102-118: first half of the batch corrupts tails, second half heads; negatives are non-edges."""
+        """task.py:102-118: first half of the batch corrupts tails, second half heads; negatives are non-edges.
+        On the device the candidates are never materialised: the ``k``-th surviving entity is found by binary search
+        in the fact graph's sorted completion keys (``csrc/sampler.inc``) -- the same entity the reference's
+        ``mask.nonzero()`` + ``variadic_sample`` returns for the same uniform numbers, with no ``(B / 2, N)`` mask, no
+        ``nonzero`` and no host synchronisation."""
         static = getattr(self, "_static_negative", None)
-        if static is not None:          # engine.GraphedTrainStep: drawn eagerly, the captured step reads this buffer
+        if static is not None:          # a caller that feeds pre-drawn negatives through a static buffer
             return static
         half = len(pos_h_index) // 2
+        ops = backend.get()
+        if ops.accepts(pos_h_index):
+            fact = self.fact_graph
+            n, r = fact.num_node, max(fact.num_relation, 1)
+            # one draw per half, in the reference's order (variadic_sample draws `torch.rand(rows, num_sample)`)
+            rand_t = torch.rand(half, self.num_negative, device=pos_h_index.device)
+            neg_t = ops.strict_negatives(fact.completion_keys(0), pos_h_index[:half], pos_r_index[:half], r, n, rand_t)
+            rand_h = torch.rand(len(pos_h_index) - half, self.num_negative, device=pos_h_index.device)
+            neg_h = ops.strict_negatives(fact.completion_keys(1), pos_t_index[half:], pos_r_index[half:], r, n, rand_h)
+            return torch.cat([neg_t, neg_h])
         t_mask = self._calculate_t_mask(self.fact_graph, pos_h_index[:half], pos_r_index[:half])
         neg_t = variadic_sample(t_mask.nonzero()[:, 1], t_mask.sum(dim=-1), self.num_negative)
         h_mask = self._calculate_h_mask(self.fact_graph, pos_t_index[half:], pos_r_index[half:])
@@ -269,16 +322,27 @@ class KnowledgeGraphCompletion(nn.Module):
         ``(B, 2, N)`` masks of ``target`` / ``get_ranking`` (task.py:279-315) remain the CPU / cross-check path."""
         if pred is None:        # (a caller that replays `predict` as a hipGraph passes its scores in)
             pred = self.predict(batch)
-        if pred.is_cuda and hasattr(layer.functional, "filtered_rank"):
-            lists, target = self.target_lists(batch)
-            if not self.filtered_ranking:
-                lists = (None, None)
-            return layer.functional.filtered_rank(pred.flatten(0, 1), target.flatten(), *lists).view(-1, 2)
+        ops = backend.get()
+        if ops.accepts(pred):
+            batch = self._select(batch)
+            pos_h_index, pos_t_index, pos_r_index = batch.t()
+            graph = self.graph
+            n_rel = max(graph.num_relation, 1)
+            keys = (graph.completion_keys(0), graph.completion_keys(1)) if self.filtered_ranking else (None, None)
+            # the filter of each side is a range of the graph's sorted completion keys, found inside the kernel:
+            # no (B, N) mask, no per-batch list building, no host synchronisation (capturable with predict)
+            t_rank = ops.filtered_rank_keys(pred[:, 0], pos_t_index, keys[0], pos_h_index, pos_r_index, n_rel)
+            h_rank = ops.filtered_rank_keys(pred[:, 1], pos_h_index, keys[1], pos_t_index, pos_r_index, n_rel)
+            return torch.stack([t_rank, h_rank], dim=1)
         return self.get_ranking(pred, self.target(batch))
 
-    def evaluate(self, ranking):
-        """task.py:317-351 on an int64 ``(n, 2)`` ranking tensor (column 0 = tail, 1 = head)."""
+    def evaluate(self, ranking, rel=None):
+        """task.py:317-351 on an int64 ``(n, 2)`` ranking tensor (column 0 = tail, 1 = head).  With
+        ``metric_per_rel`` and ``rel`` (``(n,)`` relation of every ranked triple) every undirected metric is also
+        reported per relation (task.py:290-292,512-517: tails under ``r``, heads under ``r + num_relation``)."""
         metric = {}
+        if self.metric_per_rel and rel is None:
+            raise ValueError("metric_per_rel needs the relation of every ranked triple: evaluate(ranking, rel)")
         for name in self.metric:
             _ranking, _name = ranking, name
             if "-" in name:
@@ -295,6 +359,15 @@ class KnowledgeGraphCompletion(nn.Module):
             else:
                 raise ValueError("Unknown metric `%s`" % name)
             metric[name] = score
+            if self.metric_per_rel and "-" not in name:
+                n_rel = self.num_relation
+                rel2 = torch.stack([rel, rel + n_rel], dim=1).reshape(-1).to(ranking.device)
+                value = ranking.reshape(-1).float()
+                value = value if _name == "mr" else (1 / value if _name == "mrr" else (value <= int(_name[5:])).float())
+                total = torch.zeros(2 * n_rel, device=ranking.device).index_add_(0, rel2, value)
+                count = torch.zeros(2 * n_rel, device=ranking.device).index_add_(0, rel2, torch.ones_like(value))
+                for ridx in range(2 * n_rel):
+                    metric["%s_rel_%d" % (name, ridx)] = total[ridx] / count[ridx].clamp(min=1)
         return metric
 
     # ------------------------------------------------------------------ training loss (task.py:160-195)
@@ -303,21 +376,34 @@ class KnowledgeGraphCompletion(nn.Module):
         all_loss = torch.zeros((), dtype=torch.float32, device=batch.device)
         metric = {}
         pred = self.predict(batch, all_loss, metric)
+        pos_h_index, pos_t_index, pos_r_index = batch.t()
+        names = {"bce": "binary cross entropy", "ce": "cross entropy", "ranking": "ranking loss"}
         for criterion, weight in self.criterion.items():
-            if criterion != "bce":
-                raise ValueError("Unknown criterion `%s`" % criterion)
-            target = torch.zeros_like(pred)
-            target[:, 0] = 1
-            loss = F.binary_cross_entropy_with_logits(pred, target, reduction="none")
-            neg_weight = torch.ones_like(pred)
-            if self.adversarial_temperature > 0:
-                with torch.no_grad():
-                    neg_weight[:, 1:] = F.softmax(pred[:, 1:] / self.adversarial_temperature, dim=-1)
+            if criterion == "bce":                                                   # task.py:169-180
+                target = torch.zeros_like(pred)
+                target[:, 0] = 1
+                loss = F.binary_cross_entropy_with_logits(pred, target, reduction="none")
+                neg_weight = torch.ones_like(pred)
+                if self.adversarial_temperature > 0:
+                    with torch.no_grad():
+                        neg_weight[:, 1:] = F.softmax(pred[:, 1:] / self.adversarial_temperature, dim=-1)
+                else:
+                    neg_weight[:, 1:] = 1 / self.num_negative
+                loss = (loss * neg_weight).sum(dim=-1) / neg_weight.sum(dim=-1)
+            elif criterion == "ce":                                                  # task.py:698-700
+                loss = F.cross_entropy(pred, torch.zeros(len(pred), dtype=torch.long, device=pred.device),
+                                       reduction="none")
+            elif criterion == "ranking":                                             # task.py:701-705
+                loss = F.margin_ranking_loss(pred[:, :1], pred[:, 1:], torch.ones_like(pred[:, 1:]),
+                                             margin=self.margin)
             else:
-                neg_weight[:, 1:] = 1 / self.num_negative
-            loss = (loss * neg_weight).sum(dim=-1) / neg_weight.sum(dim=-1)
+                raise ValueError("Unknown criterion `%s`" % criterion)
+            if self.sample_weight:                                                   # task.py:184-187
+                degree = self._pair_degree("hr", pos_h_index, pos_r_index) * self._pair_degree("tr", pos_t_index, pos_r_index)
+                sample_weight = 1 / degree.float().sqrt()
+                loss = (loss * sample_weight).sum() / sample_weight.sum()
             loss = loss.mean()
-            metric["binary cross entropy"] = loss
+            metric[names[criterion]] = loss
             all_loss = all_loss + loss * weight
         return all_loss, metric
 
