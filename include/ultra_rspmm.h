@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_RSPMM_ABI_VERSION 2
+#define ULTRA_RSPMM_ABI_VERSION 3
 
 /* sum= / mul= of generalized_rspmm (layer.py:134-167: sum in {"add","max","min"}, mul in {"mul","add"}) */
 enum ultra_sum_op { ULTRA_SUM_ADD = 0, ULTRA_SUM_MIN = 1, ULTRA_SUM_MAX = 2 };
@@ -80,6 +80,9 @@ typedef struct ultra_segments {
     /* the n_hot most frequently gathered nodes and n_hot + node id for all others                               */
     int64_t n_hot;
     const int32_t *hot_nodes;  /* [n_hot] */
+    /* optional row pointers [n_rows + 1] (first edge of every target row); with them, plans of big graphs (node ids  */
+    /* outside the packed word) that have no split rows run one row per 16-lane group (csrc/rowgroup.inc)           */
+    const int32_t *row_ptr;
 } ultra_segments;
 
 int ultra_rspmm_abi_version(void);
@@ -104,7 +107,8 @@ int ultra_rspmm_event_elapsed_ms(void *start_event, void *stop_event, float *ms_
 
 /* Test/bench knob (process-wide): bit 0 forces the general kernel where the packed fast paths apply, bit 1 keeps
  * them from staging a small gathered matrix in LDS, bit 2 selects one chunk per wave (packed_kernel) where four
- * chunks per wave (quad_kernel) would run.  All paths return identical bits. */
+ * chunks per wave (quad_kernel) would run, bit 3 the chunked kernels where one row per 16-lane group (rowgroup_kernel)
+ * would run.  All paths return identical bits. */
 int ultra_rspmm_force_general_path(int on);
 
 /* Scratch bytes a call over `seg` with row width F needs (piece partial sums). */
@@ -124,6 +128,18 @@ size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg_host, int64_t F);
 int ultra_rspmm_forward_f32(const ultra_segments *fwd_host, const float *relation, const float *input,
                             const float *add_rows, float *out, void *workspace, size_t workspace_bytes,
                             int64_t n_src, int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream);
+
+/*
+ * The same operator straight from a coalesced CSR, without a plan (SURVEY.md 8b's torch-free entry): rows = destination
+ * nodes, row_ptr int32 [N + 1], src / rel int32 [E] sorted by (row, src, rel), w fp32 [E] or NULL (all ones).
+ * Every row is reduced strictly sequentially in that order -- the reference order for EVERY row (no pieces), so long
+ * rows cost their length on one 16-lane group: meant for the standalone bench, for raw-CSR callers
+ * (torch.ops.ultra_mi.rspmm_fwd) and for graphs of short rows; skewed KGs should use a plan.
+ * relation [R, F], x [n_src, F], out [N, F] fp32, 16-byte aligned rows (F % 4 == 0).
+ */
+int ultra_rspmm_fwd_f32(const int32_t *row_ptr, const int32_t *src, const int32_t *rel, const float *w,
+                        const float *relation, const float *x, float *out, int64_t N, int64_t E, int64_t R, int64_t F,
+                        int sum_op, int mul_op, void *stream);
 
 /* Forward with the Bellman-Ford boundary in its sparse form (same kernels, no dense [n_rows, F] read per layer).
  * The reference builds `boundary = zeros(N, B, D); boundary.scatter_add_(0, h_index, query)` (ultra/model.py:106-107,

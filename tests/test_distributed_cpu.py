@@ -59,6 +59,33 @@ def _worker(rank, world, port, out_dir):
     dist.all_gather(gathered, grads)
     assert torch.equal(gathered[0], gathered[1])           # after the all-reduce every rank holds the same gradients
     unused = sorted(k for k, p in task.named_parameters() if p.grad is None)
+
+    # three more steps, three ways: flat blocking all-reduce | bucketed reducer launched from the backward hooks
+    # (overlap) | the same buckets launched after backward -- identical parameters afterwards, on both ranks
+    finals = {}
+    for mode in ("flat", "overlap", "after"):
+        twin, _ = _build()                                 # same seed: same initial weights in every mode
+        twin.train()
+        opt_t = torch.optim.AdamW(twin.parameters(), lr=5e-4)
+        reducer = None if mode == "flat" else engine.GradientReducer(twin, overlap=(mode == "overlap"))
+        if reducer is not None:      # never-used parameters are excluded statically, everything else is in a bucket
+            in_buckets = {n for b in reducer.buckets for n in b["names"]}
+            assert in_buckets == {k for k, _ in twin.named_parameters()} - set(unused)
+            assert [b["name"] for b in reducer.buckets][:2] == ["model.mlp", "model.layers.1"]
+        with oracle_rspmm(0):
+            for s in range(3):
+                b = triples[100 + 16 * s + 8 * rank: 108 + 16 * s + 8 * rank]
+                twin._static_negative = torch.randint(0, 120, (8, 8), generator=torch.Generator().manual_seed(7 * s + rank))
+                engine.train_step(twin, opt_t, b, reducer=reducer)
+                if reducer is not None and mode == "overlap":
+                    assert reducer._launched == 0 and reducer._next == 0          # finish() reset the state
+        finals[mode] = torch.cat([p.detach().reshape(-1) for p in twin.parameters()])
+    for mode in ("overlap", "after"):
+        diff = (finals[mode] - finals["flat"]).abs().max().item()
+        assert torch.equal(finals[mode], finals["flat"]), (mode, diff)
+    both = [torch.zeros_like(finals["flat"]) for _ in range(world)]
+    dist.all_gather(both, finals["overlap"])
+    assert torch.equal(both[0], both[1])
     torch.save(dict(ranking=ranking, mrr=metric["mrr"], loss=loss, tloss=tmetric["binary cross entropy"],
                     unused=unused, grads=grads), os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()

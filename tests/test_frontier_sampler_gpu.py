@@ -1,0 +1,319 @@
+"""GPU tests of the first-layer frontier kernel (csrc/frontier.inc) and of the key-based per-step index kernels
+(csrc/sampler.inc): filtered ranks, strict negatives and edge removal without dense masks / match() / host syncs.
+
+Bars: the frontier result must be EQUAL to the full forward kernel on the dense boundary (and to the oracle in the
+kernels' summation order); ranks, negatives and removed-edge weights are integer / exact work and must be EQUAL to
+the reference formulation (``ultra/task.py:65-118,307-315``, ``ultra/model.py:57-74``) restated with dense masks.
+"""
+import numpy as np
+import pytest
+import torch
+
+from graphs import random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a)).to(_dev())
+
+
+# ------------------------------------------------------------------------------------------------ frontier
+@pytest.mark.parametrize("case", ["uniform", "hub_split_rows_multi_relation", "weights", "kg_shape"])
+def test_frontier_equals_full_kernel_on_dense_boundary(oracle, case):
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    dev = _dev()
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    if case == "uniform":
+        n, r = 500, 9
+        g = random_graph(seed=1, n_node=n, n_edge=6000, n_rel=r)
+        opts = {}
+    elif case == "hub_split_rows_multi_relation":
+        # node 3 receives 2 000 edges (split into pieces of 64) and several source nodes reach it through MANY relations:
+        # the runs (src -> 3, *) straddle piece boundaries with more than one term on either side
+        n, r = 300, 24
+        g = random_graph(seed=2, n_node=n, n_edge=5000, n_rel=r, hub_row=3, hub_edges=2000)
+        for s in (7, 8, 9):
+            extra = np.arange(r, dtype=np.int64)
+            g["dst"] = np.concatenate([g["dst"], np.full(r, 3)])
+            g["src"] = np.concatenate([g["src"], np.full(r, s)])
+            g["rel"] = np.concatenate([g["rel"], extra])
+        opts = dict(chunk_edges=16, piece_len=64)
+    elif case == "weights":
+        n, r = 400, 7
+        g = random_graph(seed=3, n_node=n, n_edge=9000, n_rel=r, weights=True, skew=True)
+        opts = {}
+    else:
+        from graphs import kg_graph
+        n, r = 14541, 474
+        g = kg_graph(1024, n, 272115, 237)
+        opts = {}
+    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), None if g["w"] is None else _t(g["w"]), n, n, r, **opts)
+    B = 6
+    F = B * 64
+    relation = torch.from_numpy(rng.standard_normal((r, F)).astype(np.float32)).to(dev)
+    value = torch.from_numpy(rng.standard_normal((B, 64)).astype(np.float32)).to(dev)
+    if case == "hub_split_rows_multi_relation":
+        nodes = [7, 8, 9, 3, 7, 250]            # sources of the multi-relation runs, the hub itself, a repeat
+    else:
+        deg_out = torch.bincount(csr.src, minlength=n)
+        nodes = [int(deg_out.argmax()), int((deg_out == 0).nonzero()[0]) if (deg_out == 0).any() else 1, 0, n - 1, 5, 5]
+    node = torch.tensor(nodes, dtype=torch.int32, device=dev)
+    dense = torch.zeros(n, B, 64, device=dev)
+    dense[node.long(), torch.arange(B, device=dev)] = value                  # model.py:106-107
+    dense = dense.flatten(1)
+
+    got = UF.rspmm_frontier(csr, relation, (node, value))
+    want = UF.rspmm_forward(csr, relation, dense, "add", "mul", boundary=(node, value))
+    assert torch.equal(got, want), "frontier differs from the full kernel: max |diff| %.3g" % (got - want).abs().max()
+    want_dense_add = UF.rspmm_forward(csr, relation, dense, "add", "mul", add_rows=dense)
+    assert torch.equal(got, want_dense_add)
+    if n <= 1000:
+        csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+        want_o = oracle.rspmm_forward(csr_o, relation.cpu().numpy(), dense.cpu().numpy(), "add", "mul", piece=csr.piece_len)
+        assert np.array_equal(got.cpu().numpy(), want_o + dense.cpu().numpy())
+
+
+def test_first_layer_uses_the_frontier_and_predict_is_unchanged():
+    """task.predict with and without the first-layer shortcut: identical scores (the shortcut is bit-compatible)."""
+    from ultra_torchdrug_amd import layer
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    triples, n, r = synthetic_triples((1200, 9000, 12), 1024)
+    torch.manual_seed(1024)
+    task = build_ultra(r)
+    task.preprocess(Graph(torch.from_numpy(triples), num_node=n, num_relation=r))
+    task.to(_dev()).eval()
+    batch = _t(triples[:16])
+    calls = []
+    real = layer.backend.get().rspmm_frontier
+    from ultra_torchdrug_amd import functional as UF
+    UF.rspmm_frontier = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            with_frontier = task.predict(batch)
+            layer.FRONTIER_FIRST_LAYER = False
+            n_calls = len(calls)
+            without = task.predict(batch)
+    finally:
+        layer.FRONTIER_FIRST_LAYER = True
+        UF.rspmm_frontier = real
+    assert n_calls == 2 and len(calls) == 2            # entity stack + relation stack, first layer each
+    assert torch.equal(with_frontier, without)
+
+
+# ------------------------------------------------------------------------------------------------ sampler
+def _kg(n=700, triples=6000, r=9, seed=4):
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    tr, n, r = synthetic_triples((n, triples, r), seed)
+    tr = np.concatenate([tr, tr[:50]])                  # duplicate fact edges: filters must stay DISTINCT lists
+    return Graph(torch.from_numpy(tr).to(_dev()), num_node=n, num_relation=r), tr
+
+
+def test_filtered_rank_from_keys_equals_dense_mask_ranking():
+    from ultra_torchdrug_amd import functional as UF
+    from ultra_torchdrug_amd.task import build_ultra
+    graph, tr = _kg()
+    task = build_ultra(graph.num_relation)
+    task.preprocess(graph)
+    dev = _dev()
+    batch = _t(tr[:33])
+    gen = torch.Generator(device=dev).manual_seed(1)
+    pred = (torch.randn(33, 2, graph.num_node, device=dev, generator=gen) * 4).round() / 4        # many exact ties
+    mask, target = task.target(batch)
+    want = task.get_ranking(pred, (mask, target))
+    got = task.rank_batch(batch, pred=pred)
+    assert got.dtype == torch.int64 and torch.equal(got, want)
+    task.filtered_ranking = False
+    assert torch.equal(task.rank_batch(batch, pred=pred), task.get_ranking(pred, (mask, target)))
+    # the lists the older entry point takes describe the same filter
+    task.filtered_ranking = True
+    (ptr, node), _ = task.target_lists(batch)
+    assert torch.equal(UF.filtered_rank(pred.flatten(0, 1), target.flatten(), ptr, node).view(-1, 2), want)
+
+
+def test_strict_negatives_from_keys_equal_the_reference_sampler():
+    """Same uniform numbers in, same negatives out as mask.nonzero() + variadic_sample (task.py:102-118)."""
+    from ultra_torchdrug_amd import functional as UF
+    from ultra_torchdrug_amd.task import build_ultra, variadic_sample
+    graph, tr = _kg()
+    task = build_ultra(graph.num_relation, num_negative=32)
+    task.preprocess(graph)
+    dev = _dev()
+    batch = _t(tr[100:164])
+    h, t, r = batch.t()
+    half = len(batch) // 2
+    torch.manual_seed(9)
+    got = task._strict_negative(h, t, r)
+    # the reference formulation, fed the same random stream
+    torch.manual_seed(9)
+    t_mask = task._calculate_t_mask(task.fact_graph, h[:half], r[:half])
+    rand = torch.rand(half, 32, device=dev)
+    sizes = t_mask.sum(dim=-1)
+    idx = (rand * sizes.unsqueeze(-1)).long() + (sizes.cumsum(0) - sizes).unsqueeze(-1)
+    neg_t = t_mask.nonzero()[:, 1][idx]
+    h_mask = task._calculate_h_mask(task.fact_graph, t[half:], r[half:])
+    rand = torch.rand(len(batch) - half, 32, device=dev)
+    sizes = h_mask.sum(dim=-1)
+    idx = (rand * sizes.unsqueeze(-1)).long() + (sizes.cumsum(0) - sizes).unsqueeze(-1)
+    neg_h = h_mask.nonzero()[:, 1][idx]
+    assert got.shape == (64, 32) and torch.equal(got, torch.cat([neg_t, neg_h]))
+    assert t_mask.gather(1, got[:half]).all() and h_mask.gather(1, got[half:]).all()        # strict: never a fact
+    # extremes of the uniform numbers and a row whose every entity but one is a known completion
+    n, nr = graph.num_node, graph.num_relation
+    star = torch.stack([torch.zeros(n - 1, dtype=torch.long), torch.arange(1, n), torch.zeros(n - 1, dtype=torch.long)], 1)
+    from ultra_torchdrug_amd.graph import Graph
+    g2 = Graph(star.to(dev), num_node=n, num_relation=nr)
+    edge = torch.tensor([[0.0, 0.5, 0.99999994]], device=dev)
+    out = UF.strict_negatives(g2.completion_keys(0), torch.zeros(1, dtype=torch.long, device=dev),
+                              torch.zeros(1, dtype=torch.long, device=dev), nr, n, edge)
+    assert out.tolist() == [[0, 0, 0]]                  # node 0 is the only non-completion of (0, 0, ?)
+    out = UF.strict_negatives(g2.completion_keys(0), torch.ones(1, dtype=torch.long, device=dev),
+                              torch.zeros(1, dtype=torch.long, device=dev), nr, n, edge)
+    assert out.tolist() == [[0, n // 2, n - 1]]         # nothing known about (1, 0, ?): plain floor(rand * n)
+
+
+def test_native_edge_removal_equals_mask_and_reweight_path():
+    """Graph.without_triples (one native call) against the reference's way (model.py:57-74: match + edge_mask, then
+    undirected): the weights of all three plans, the forward result and both gradients."""
+    from ultra_torchdrug_amd import functional as UF
+    from ultra_torchdrug_amd.graph import Graph
+    graph, tr = _kg()
+    dev = _dev()
+    n, r = graph.num_node, graph.num_relation
+    und = graph.undirected(add_inverse=True)
+    pos = _t(tr[:20])
+    gen = torch.Generator(device=dev).manual_seed(2)
+    # the pattern grid of a training batch: positives in column 0, (strict) negatives elsewhere -- those match nothing
+    h = pos[:, 0:1].repeat(1, 5)
+    t = pos[:, 1:2].repeat(1, 5)
+    rr = pos[:, 2:3].repeat(1, 5)
+    t[:, 1:] = torch.randint(0, n, (20, 4), device=dev, generator=gen)
+    edge_index = graph.match(torch.stack([h, t, rr], dim=-1).flatten(0, 1))[0]
+    keep = torch.ones(graph.num_edge, dtype=torch.bool, device=dev)
+    keep[edge_index] = False
+    assert int((~keep).sum()) >= 20
+    want_graph = und.reweighted(und.edge_weight * keep.repeat_interleave(2))
+    got_graph = und.without_triples(h, t, rr, r)
+    for plan in ("fwd", "by_src", "by_rel"):
+        a, b = getattr(got_graph.relcsr, plan), getattr(want_graph.relcsr, plan)
+        assert torch.equal(a.weight, b.weight), plan
+        assert a.chunks.data_ptr() == getattr(und.relcsr, plan).chunks.data_ptr()        # plans shared, not rebuilt
+    F = 128
+    relation = torch.randn(2 * r, F, device=dev, generator=gen).requires_grad_()
+    x = torch.randn(n, F, device=dev, generator=gen).requires_grad_()
+    grad = torch.randn(n, F, device=dev, generator=gen)
+    outs = []
+    for g in (got_graph, want_graph, Graph(und.edge_list[keep.repeat_interleave(2)], None, n, 2 * r)):
+        relation.grad = x.grad = None
+        out = UF.generalized_rspmm(g.relcsr, relation, x)
+        out.backward(grad)
+        outs.append((out.detach(), relation.grad.clone(), x.grad.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0], outs[2]):                  # really removing the edges: same sums up to the order of +0.0
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    # reweighting a reweighted graph keeps working through the backward (plans come from the base object)
+    twice = want_graph.reweighted(want_graph.edge_weight * 0.5)
+    relation.grad = x.grad = None
+    UF.generalized_rspmm(twice.relcsr, relation, x).backward(grad)
+    torch.testing.assert_close(x.grad, 0.5 * outs[1][2], rtol=1e-6, atol=1e-6)
+
+
+def test_graphed_train_step_captures_negatives_and_edge_removal():
+    """With the sampler and the edge removal on the device, a whole fine-tuning step (negatives, edge removal, forward,
+    backward) replays as ONE hipGraph; same losses and parameters as eager steps fed the same random stream."""
+    import copy
+    from ultra_torchdrug_amd import engine
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    triples, n, r = synthetic_triples("S-tiny", 1024)
+    torch.manual_seed(1024)
+    task = build_ultra(r, num_negative=16)
+    task.preprocess(Graph(torch.from_numpy(triples), num_node=n, num_relation=r))
+    dev = _dev()
+    task.to(dev).train()
+    twin = copy.deepcopy(task)
+    batches = [_t(triples[i:i + 8]) for i in (0, 8, 16, 24)]
+    opt_g = torch.optim.AdamW(twin.parameters(), lr=1e-3)
+    step = engine.GraphedTrainStep(twin, opt_g, batches[0])
+    losses_g, negs = [], []
+    for b in batches[1:]:
+        losses_g.append(step(b)[0].item())
+        negs.append(step.last_negatives.clone())
+    opt_e = torch.optim.AdamW(task.parameters(), lr=1e-3)
+    losses_e = []
+    for b, neg in zip(batches[1:], negs):
+        task._static_negative = neg                    # the graph drew its own negatives: replay them eagerly
+        losses_e.append(engine.train_step(task, opt_e, b)[0].item())
+    task._static_negative = None
+    assert losses_g == losses_e
+    for (k, a), (_, b) in zip(task.named_parameters(), twin.named_parameters()):
+        assert torch.equal(a, b), k
+    assert not torch.equal(negs[0], negs[1])            # the captured RNG advances between replays
+
+
+# ------------------------------------------------------------------------------------------------ rowgroup / raw CSR
+@pytest.mark.parametrize("case", ["short_rows", "weights_many_relations", "ragged_with_empty_rows"])
+def test_rowgroup_kernel_and_raw_csr_entry_match_oracle(oracle, case):
+    """One row per 16-lane group (csrc/rowgroup.inc): (i) as the kernel run_plan picks for big-graph plans without split
+    rows (forced on small graphs with wide_ids=True), against the chunked kernels (knob bit 3) and the oracle; (ii) as
+    the raw-CSR entry ultra_rspmm_fwd_f32, whose order is the strictly sequential reference order for every row."""
+    from ultra_torchdrug_amd import RelCSR, _lib, functional as UF
+    dev = _dev()
+    if case == "short_rows":
+        n, r, F = 3000, 40, 64
+        g = random_graph(seed=5, n_node=n, n_edge=30000, n_rel=r)
+    elif case == "weights_many_relations":
+        n, r, F = 700, 900, 128          # relation tile does not fit LDS: rows through L2
+        g = random_graph(seed=6, n_node=n, n_edge=9000, n_rel=r, weights=True)
+    else:
+        n, r, F = 500, 5, 192
+        g = random_graph(seed=7, n_node=n, n_edge=6000, n_rel=r, isolated=120, skew=True, hub_row=9, hub_edges=100)
+    rng = np.random.default_rng(1)
+    relation = rng.standard_normal((r, F)).astype(np.float32)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    grad = rng.standard_normal((n, F)).astype(np.float32)
+    csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
+    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), None if g["w"] is None else _t(g["w"]), n, n, r,
+                 wide_ids=True, piece_len=512, chunk_edges=128)
+    assert csr.fwd.packed_src_shift == 32 and csr.fwd.row_ptr is not None and csr.fwd.n_pieces == 0
+    lib = _lib.load()
+    rel_t, x_t, g_t = _t(relation), _t(x), _t(grad)
+    for s in ("add", "min", "max"):
+        for m in ("mul", "add"):
+            want = oracle.rspmm_forward(csr_o, relation, x, s, m, piece=0)
+            got = UF.rspmm_forward(csr, rel_t, x_t, s, m)
+            lib.ultra_rspmm_force_general_path(8)
+            try:
+                chunked = UF.rspmm_forward(csr, rel_t, x_t, s, m)
+            finally:
+                lib.ultra_rspmm_force_general_path(0)
+            assert np.array_equal(got.cpu().numpy(), want), (s, m)
+            assert torch.equal(got, chunked), (s, m)
+            raw = UF.rspmm_forward_csr(csr.fwd.row_ptr, csr.fwd.node_a[:csr.n_edges], csr.fwd.rel,
+                                       None if csr.unit_weight else csr.weight, rel_t, x_t, s, m)
+            assert np.array_equal(raw.cpu().numpy(), want), ("raw", s, m)
+    # fused boundary epilogues ride along as in the chunked kernels
+    node = torch.tensor([1, 17, 3][:F // 64], dtype=torch.int32, device=dev)
+    value = torch.randn(F // 64, 64, device=dev)
+    with_b = UF.rspmm_forward(csr, rel_t, x_t, "add", "mul", boundary=(node, value))
+    lib.ultra_rspmm_force_general_path(8)
+    try:
+        assert torch.equal(with_b, UF.rspmm_forward(csr, rel_t, x_t, "add", "mul", boundary=(node, value)))
+    finally:
+        lib.ultra_rspmm_force_general_path(0)
+    # d_input through the same kernel (rows = source nodes, gathers output_grad)
+    for m in ("mul", "add"):
+        out = oracle.rspmm_forward(csr_o, relation, x, "add", m, piece=0)
+        d_rel_o, d_x_o = oracle.rspmm_backward(csr_o, relation, x, out, grad, "add", m, piece=csr.piece_len)
+        d_x, d_rel = UF.rspmm_backward(csr, rel_t, x_t, None, g_t, "add", m)
+        assert np.array_equal(d_x.cpu().numpy(), d_x_o) and np.array_equal(d_rel.cpu().numpy(), d_rel_o), m

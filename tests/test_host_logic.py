@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.ultra_rspmm_abi_version() == version == _lib.ABI_VERSION
     assert lib.ultra_rspmm_status_string(1).decode().startswith("unknown sum/mul")
     import ctypes
-    assert ctypes.sizeof(_lib.UltraSegments) == 17 * 8          # struct layout of the header
+    assert ctypes.sizeof(_lib.UltraSegments) == 18 * 8          # struct layout of the header
 
 
 def test_operator_rejects_cpu_tensors_and_bad_names():

@@ -1,0 +1,222 @@
+"""GPU parity against the REFERENCE'S OWN in-tree definition of the operator -- no C oracle in between.
+
+``generalized_rspmm`` lives in torchdrug (un-vendored), but the reference also carries the operator's O(E)
+definition as plain ATen code: ``message`` + ``aggregate`` (``/root/reference/ultra/layer.py:232-296``, twin
+``:52-109``), the branch it takes for ``rotate`` messages or graphs that require grad (``:299``).  Two levels:
+
+* operator level: the six (sum, mul) pairs of ``generalized_rspmm`` against a restatement of those lines written
+  here with torch ops on the GPU (gather, (+|*), ``* edge_weight``, ``scatter_reduce``), at the BASELINE shapes
+  S-fb15k237 (B = 2) and S-wn18rr (B = 2), forward and backward;
+* layer / model level: the package's ``TransferNBFNet`` and ``RelNBFNet`` layers once through the ATen
+  ``message`` + ``aggregate`` branch (``graph.requires_grad = True``) and once through the HIP rspmm, so that a bug
+  in the wrapper code around the kernels (reshape, transpose, boundary handling, relation tables, the first-layer
+  frontier shortcut) cannot cancel out.
+
+Tolerances (fp32): min / max do not depend on the summation order and the message arithmetic is one rounding in both
+formulations, so they must be EQUAL; sums differ only in the order of fp32 additions (``scatter_add`` uses atomics):
+``|diff| <= 1e-5 * S + 1e-6`` with ``S`` the same reduction over absolute values (the sum of |terms|).
+"""
+import numpy as np
+import pytest
+import torch
+
+from graphs import kg_graph
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {"S-fb15k237": (14541, 272115, 237), "S-wn18rr": (40943, 86835, 11)}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _graph(name, weights):
+    n, triples, base_rel = SHAPES[name]
+    g = kg_graph(1024, n, triples, base_rel)
+    dev = _dev()
+    dst, src, rel = (torch.from_numpy(g[k]).to(dev) for k in ("dst", "src", "rel"))
+    # distinct triples: ties between duplicate messages make the min/max gradient a convention, not a definition
+    key = torch.unique((dst * n + src) * (2 * base_rel) + rel)
+    rel, key = key % (2 * base_rel), key // (2 * base_rel)
+    src, dst = key % n, key // n
+    w = None
+    if weights:
+        gen = torch.Generator(device=dev).manual_seed(5)
+        w = torch.rand(len(dst), device=dev, generator=gen) * 1.75 + 0.25
+    return dst, src, rel, w, n, 2 * base_rel
+
+
+def reference_rspmm(dst, src, rel, w, relation, x, n_rows, sum, mul):
+    """ultra/layer.py:249-255 (message) and :270-285 (aggregate) without the boundary rows, in torch ops."""
+    node_input = x[src]                                                    # layer.py:249
+    edge_input = relation[rel]                                             # layer.py:250
+    message = edge_input + node_input if mul == "add" else edge_input * node_input     # :252-255
+    if w is not None:
+        message = message * w.unsqueeze(-1)                                # layer.py:275
+    index = dst.unsqueeze(-1).expand_as(message)
+    reduce = {"add": "sum", "max": "amax", "min": "amin"}[sum]             # scatter_add / scatter_max / scatter_min
+    out = torch.zeros(n_rows, x.shape[1], device=x.device, dtype=x.dtype)
+    return out.scatter_reduce(0, index, message, reduce=reduce, include_self=False)
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+@pytest.mark.parametrize("weights", [False, True])
+@pytest.mark.parametrize("sum", ["add", "min", "max"])
+@pytest.mark.parametrize("mul", ["mul", "add"])
+def test_operator_equals_reference_definition_at_baseline_shapes(name, weights, sum, mul):
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    dev = _dev()
+    dst, src, rel, w, n, n_rel = _graph(name, weights)
+    F = 2 * 64                                                             # B = 2 queries
+    gen = torch.Generator(device=dev).manual_seed(11)
+    relation = torch.randn(n_rel, F, device=dev, generator=gen).requires_grad_()
+    x = torch.randn(n, F, device=dev, generator=gen).requires_grad_()
+    grad = torch.randn(n, F, device=dev, generator=gen)
+    csr = RelCSR(dst, src, rel, w, n, n, n_rel)
+    assert csr.n_edges == len(dst)
+
+    out = UF.generalized_rspmm(csr, relation, x, sum=sum, mul=mul)
+    out.backward(grad)
+    d_rel, d_x = relation.grad.clone(), x.grad.clone()
+    relation.grad = x.grad = None
+
+    want = reference_rspmm(dst, src, rel, w, relation, x, n, sum, mul)
+    deg = torch.bincount(dst, minlength=n)
+    has_edges = (deg > 0).unsqueeze(-1)
+    # rows without edges: scatter_reduce leaves its zero fill, the operator its identity -- compare rows with edges
+    # (in the layers every node receives the boundary self-message, so the difference never arises there)
+    want.backward(grad * has_edges)
+    want_d_rel, want_d_x = relation.grad.clone(), x.grad.clone()
+
+    rows = has_edges.expand_as(out)
+    if sum == "add":
+        with torch.no_grad():
+            scale = reference_rspmm(dst, src, rel, None if w is None else w.abs(), relation.abs(), x.abs(), n, "add", mul)
+        assert ((out - want).abs() <= 1e-5 * scale + 1e-6)[rows].all()
+        assert (out[~rows] == 0).all()
+        # gradients are sums of the same kind: bound them by the same reduction over absolute values
+        with torch.no_grad():
+            ones = torch.ones_like(x)
+            g_abs = grad.abs() * has_edges
+            rel_of = relation.abs() if mul == "mul" else torch.ones_like(relation)
+            x_of = x.abs() if mul == "mul" else ones
+            wa = torch.ones(len(dst), device=dev) if w is None else w.abs()
+            s_x = torch.zeros_like(x).index_add_(0, src, g_abs[dst] * rel_of[rel] * wa.unsqueeze(-1))
+            s_rel = torch.zeros_like(relation).index_add_(0, rel, g_abs[dst] * x_of[src] * wa.unsqueeze(-1))
+        assert ((d_x - want_d_x).abs() <= 1e-5 * s_x + 1e-6).all()
+        assert ((d_rel - want_d_rel).abs() <= 1e-5 * s_rel + 1e-5).all()
+    else:
+        assert torch.equal(out[rows], want[rows]), "min/max differ from the reference definition"
+        fmax = torch.finfo(torch.float32).max
+        assert (out[~rows] == (fmax if sum == "min" else -fmax)).all()
+        # the selected edge receives the gradient in both formulations (distinct random messages: no ties)
+        torch.testing.assert_close(d_x, want_d_x, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(d_rel, want_d_rel, rtol=1e-4, atol=1e-3)
+
+
+def _entity_model(aggregate_func, message_func, n_rel_base, layers=3):
+    from ultra_torchdrug_amd.model import TransferNBFNet
+    return TransferNBFNet(input_dim=64, hidden_dims=[64] * layers, num_relation=n_rel_base, message_func=message_func,
+                          aggregate_func=aggregate_func, short_cut=True, layer_norm=True, project=True, mod=True)
+
+
+@pytest.mark.parametrize("name,layers", [("S-fb15k237", 6), ("S-wn18rr", 6)])
+def test_entity_stack_hip_path_equals_aten_definition_path(name, layers):
+    """6 x 64d TransferNBFNet (the shipped architecture) at BASELINE size, B = 2: node features through the HIP rspmm
+    (inference path: fused boundary, first-layer frontier, grouped relation tables) against the ATen
+    message + aggregate branch of the same layers (ultra/layer.py:232-296)."""
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    dev = _dev()
+    triples, n, r = synthetic_triples(name, 1024)
+    torch.manual_seed(1024)
+    model = _entity_model("sum", "distmult", r, layers).to(dev).eval()
+    graph = Graph(torch.from_numpy(triples).to(dev), num_node=n, num_relation=r)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    B = 2
+    rel_repr = torch.randn(B, 2 * r, 64, device=dev, generator=gen)          # per-query relation representations
+    h_index = torch.randint(0, n, (B,), device=dev, generator=gen)
+    r_index = torch.randint(0, 2 * r, (B,), device=dev, generator=gen)
+    model.query = rel_repr
+    for conv in model.layers:
+        conv.relation = rel_repr
+    und = model._undirected(graph)
+    with torch.no_grad():
+        hip = model.bellmanford(und, h_index, r_index)["node_feature"]
+        aten = model.bellmanford(und, h_index, r_index, separate_grad=True)["node_feature"]
+    assert hip.shape == aten.shape == (n, B, 128)
+    scale = aten.abs().max().item()
+    diff = (hip - aten).abs().max().item()
+    assert diff <= 2e-4 * scale, "HIP path and ATen definition path differ by %.3g (scale %.3g)" % (diff, scale)
+
+
+@pytest.mark.parametrize("aggregate_func", ["sum", "mean", "max", "pna"])
+@pytest.mark.parametrize("message_func", ["distmult", "transe"])
+def test_every_aggregate_and_message_of_the_layers_matches_the_aten_definition(aggregate_func, message_func):
+    """All aggregate functions (sum / mean / max / pna = mean, max, min, std) x both rspmm messages of
+    GeneralizedRelationalConvNBFMod on S-wn18rr (B = 2), forward AND parameter / input gradients."""
+    if aggregate_func == "pna" and message_func == "transe":
+        pytest.skip("the reference's own two branches disagree here: its rspmm branch squares the OPERANDS for the "
+                    "std term (ultra/layer.py:367), not the message (:287-288); mirrored as is")
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    dev = _dev()
+    triples, n, r = synthetic_triples("S-wn18rr", 1024)
+    B = 2
+    results = {}
+    for path in ("hip", "aten"):
+        torch.manual_seed(7)
+        model = _entity_model(aggregate_func, message_func, r, layers=2).to(dev).train()
+        graph = model._undirected(Graph(torch.from_numpy(triples).to(dev), num_node=n, num_relation=r))
+        gen = torch.Generator(device=dev).manual_seed(3)
+        rel_repr = torch.randn(B, 2 * r, 64, device=dev, generator=gen).requires_grad_()
+        h_index = torch.randint(0, n, (B,), device=dev, generator=gen)
+        r_index = torch.randint(0, 2 * r, (B,), device=dev, generator=gen)
+        probe = torch.randn(n, B, 128, device=dev, generator=gen)
+        model.query = rel_repr
+        for conv in model.layers:
+            conv.relation = rel_repr
+        feature = model.bellmanford(graph, h_index, r_index, separate_grad=(path == "aten"))["node_feature"]
+        (feature * probe).sum().backward()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        grads["relation_representations"] = rel_repr.grad.clone()
+        results[path] = (feature.detach(), grads)
+    f_hip, g_hip = results["hip"]
+    f_aten, g_aten = results["aten"]
+    scale = f_aten.abs().max().item()
+    if aggregate_func == "pna":
+        # std = sqrt(clamp(E[m^2] - E[m]^2, eps = 1e-6)) (layer.py:288-289): the subtraction cancels, and the square root
+        # at the clamp amplifies a rounding difference by 1 / (2 sqrt(eps)) = 500 -- and its derivative jumps from 0 to
+        # 500 across the clamp, so the gradients of the two (equally valid) summation orders are not comparable
+        assert (f_hip - f_aten).abs().max().item() <= 2e-3 * scale
+        return
+    assert (f_hip - f_aten).abs().max().item() <= 2e-4 * scale
+    assert g_hip.keys() == g_aten.keys() and "layers.0.linear.weight" in g_hip
+    for k in g_aten:
+        s = g_aten[k].abs().max().item() + 1e-8
+        assert (g_hip[k] - g_aten[k]).abs().max().item() <= 5e-4 * s + 1e-6, k
+
+
+def test_relation_stack_hip_path_equals_aten_definition_path():
+    """RelNBFNet (GeneralizedRelationalConvNBF, dependent=False; ultra/rel_model.py:320-378) on the relation graph of
+    S-fb15k237 (474 relation nodes, 4 edge types): HIP rspmm path vs ATen message + aggregate."""
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.rel_model import RelNBFNet, construct_relation_graph
+    dev = _dev()
+    triples, n, r = synthetic_triples("S-fb15k237", 1024)
+    torch.manual_seed(1024)
+    model = RelNBFNet(input_dim=64, hidden=64, num_layers=6, num_relation=2 * r).to(dev).eval()
+    rel_graph = construct_relation_graph(Graph(torch.from_numpy(triples).to(dev), num_node=n, num_relation=r))
+    assert rel_graph.num_node == 2 * r and rel_graph.num_relation == 4
+    r_idx = torch.tensor([3, 250], device=dev)
+    with torch.no_grad():
+        hip = model(rel_graph, None, r_idx)["node_feature"]
+        rel_graph.requires_grad = True                    # layer.py:299 -> message + aggregate
+        aten = model(rel_graph, None, r_idx)["node_feature"]
+        rel_graph.requires_grad = False
+    assert hip.shape == aten.shape == (2, 2 * r, 64)
+    scale = aten.abs().max().item()
+    assert (hip - aten).abs().max().item() <= 2e-4 * scale

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ULTRA_RSPMM_LIB: load another build of the same ABI (kernel A/B runs, tools/kbench.py)
 LIB_PATH = os.environ.get("ULTRA_RSPMM_LIB") or os.path.join(_HERE, "libultra_rspmm.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SUM_OPS = {"add": 0, "min": 1, "max": 2}
 MUL_OPS = {"mul": 0, "add": 1}
@@ -35,6 +35,7 @@ class UltraSegments(ctypes.Structure):
         ("packed_src_shift", ctypes.c_int64),
         ("n_hot", ctypes.c_int64),
         ("hot_nodes", ctypes.c_void_p),
+        ("row_ptr", ctypes.c_void_p),
     ]
 
 
@@ -50,6 +51,7 @@ EXPORTS = (
     "ultra_rspmm_force_general_path",
     "ultra_rspmm_workspace_bytes",
     "ultra_rspmm_forward_f32",
+    "ultra_rspmm_fwd_f32",
     "ultra_rspmm_forward_boundary_f32",
     "ultra_rspmm_frontier_f32",
     "ultra_rspmm_backward_f32",
@@ -119,6 +121,8 @@ def load():
     lib.ultra_rspmm_workspace_bytes.argtypes = [seg, i64]
     lib.ultra_rspmm_forward_f32.restype = i32
     lib.ultra_rspmm_forward_f32.argtypes = [seg, vp, vp, vp, vp, vp, sz, i64, i64, i64, i32, i32, vp]
+    lib.ultra_rspmm_fwd_f32.restype = i32
+    lib.ultra_rspmm_fwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_forward_boundary_f32.restype = i32
     lib.ultra_rspmm_forward_boundary_f32.argtypes = [seg, vp, vp, vp, vp, i64, vp, vp, sz, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_frontier_f32.restype = i32

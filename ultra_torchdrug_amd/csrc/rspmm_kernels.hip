@@ -599,6 +599,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(const FixParams p) {
 
 #include "quad.inc"
 #include "frontier.inc"
+#include "rowgroup.inc"
 
 // d_weight[e] = sum_f (grad[dst,f] * dmask) * (relation[rel,f] MUL input[src,f]); one wave per edge.
 template <int SUM, int MUL, bool UNIT_W>
@@ -915,10 +916,10 @@ int ensure_lds_attribute(const void *kern, size_t lds) {
 }
 
 template <typename Kern, typename Params>
-int launch_with_lds(Kern kern, const Params &p, int grid, size_t lds, hipStream_t stream) {
+int launch_with_lds(Kern kern, const Params &p, int grid, size_t lds, hipStream_t stream, int block = kBlock) {
     const int rc = ensure_lds_attribute(reinterpret_cast<const void *>(kern), lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, p);
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
 }
@@ -1046,6 +1047,45 @@ int launch_quad(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_ld
     return ULTRA_ERR_BAD_OP;
 }
 
+// rowgroup_kernel dispatch.  backward: the d_input contribution order; needs_rel: a relation operand exists.
+template <int SUM, int MUL, bool BACKWARD>
+int launch_rowgroup_w(const RowGroupParams &p, bool unit_w, bool rel_lds, bool needs_rel, int grid, size_t lds,
+                      hipStream_t stream) {
+#define ULTRA_RG(UW, RL, NR) return launch_with_lds(rowgroup_kernel<SUM, MUL, UW, RL, NR, BACKWARD>, p, grid, lds, stream, kRgBlock)
+    if (!needs_rel) {
+        if (unit_w) ULTRA_RG(true, false, false);
+        ULTRA_RG(false, false, false);
+    }
+    if (unit_w) {
+        if (rel_lds) ULTRA_RG(true, true, true);
+        ULTRA_RG(true, false, true);
+    }
+    if (rel_lds) ULTRA_RG(false, true, true);
+    ULTRA_RG(false, false, true);
+#undef ULTRA_RG
+}
+
+int launch_rowgroup(const RowGroupParams &p, bool backward, int sum_op, int mul_op, bool unit_w, bool rel_lds, int grid,
+                    size_t lds, hipStream_t stream) {
+    if (backward) {       // d_input of sum-aggregation: the relation operand exists only for mul = mul
+        if (mul_op == ULTRA_MUL_MUL)
+            return launch_rowgroup_w<ULTRA_SUM_ADD, ULTRA_MUL_MUL, true>(p, unit_w, rel_lds, true, grid, lds, stream);
+        return launch_rowgroup_w<ULTRA_SUM_ADD, ULTRA_MUL_ADD, true>(p, unit_w, false, false, grid, kLdsHeader, stream);
+    }
+#define ULTRA_RCASE(S, M) \
+    if (sum_op == S && mul_op == M) return launch_rowgroup_w<S, M, false>(p, unit_w, rel_lds, true, grid, lds, stream);
+    ULTRA_RCASE(ULTRA_SUM_ADD, ULTRA_MUL_MUL)
+    ULTRA_RCASE(ULTRA_SUM_ADD, ULTRA_MUL_ADD)
+    ULTRA_RCASE(ULTRA_SUM_MIN, ULTRA_MUL_MUL)
+    ULTRA_RCASE(ULTRA_SUM_MIN, ULTRA_MUL_ADD)
+    ULTRA_RCASE(ULTRA_SUM_MAX, ULTRA_MUL_MUL)
+    ULTRA_RCASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
+#undef ULTRA_RCASE
+    return ULTRA_ERR_BAD_OP;
+}
+
+bool g_no_rowgroup = false;
+
 // Runs one plan: segment_kernel over the chunk schedule, then fixup_kernel over the split rows.
 template <int KIND>
 int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t gather2_rows, int64_t n_rel, int64_t F,
@@ -1097,10 +1137,46 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
     }
     auto stamp = [&](hipEvent_t ev) -> hipError_t { return hipEventRecord(ev, stream); };
     if (ev_start != nullptr) HIP_TRY(stamp(ev_start));
+    // big graphs of short rows (node ids outside the packed word, no split rows, row pointers present): one row per
+    // 16-lane group (rowgroup.inc); same sequential order per row as every other kernel, so the same bits
+    bool use_rowgroup = false;
+    if constexpr (KIND != KIND_DREL) {
+        auto aligned16 = [](const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; };
+        const float *gather = (KIND == KIND_DX) ? p.grad : p.input;
+        use_rowgroup = !g_force_general && !g_no_rowgroup && seg->row_ptr != nullptr && seg->packed_src_shift >= 32 &&
+                       seg->n_long_rows == 0 && (F % 4) == 0 && (KIND == KIND_FWD || sum_op == ULTRA_SUM_ADD) &&
+                       aligned16(gather) && aligned16(p.out) && aligned16(p.relation) && aligned16(p.add_rows) &&
+                       aligned16(p.bvec) && (p.bnode == nullptr || p.bdim % 4 == 0);
+        if (use_rowgroup) {
+            RowGroupParams q{};
+            q.row_ptr = seg->row_ptr;
+            q.col = seg->node_a;
+            q.rel = seg->rel;
+            q.weight = seg->weight;
+            q.relation = p.relation;
+            q.gather = gather;
+            q.add_rows = p.add_rows;
+            q.bnode = p.bnode;
+            q.bvec = p.bvec;
+            q.bdim = p.bdim;
+            q.out = p.out;
+            q.F = F;
+            q.n_rows = (int)seg->n_rows;
+            q.n_rel = (int)n_rel;
+            q.n_tiles = n_tiles;
+            q.split = split;
+            q.n_slots = p.n_slots;
+            q.blocks_per_label = blocks_per_label;
+            const bool rel_fits = n_rel > 0 && lds_need <= (size_t)kMaxLdsBytes;
+            rc = launch_rowgroup(q, KIND == KIND_DX, sum_op, mul_op, seg->weight == nullptr, rel_fits, grid,
+                                 kLdsHeader + (rel_fits ? lds_need : 0), stream);
+            if (rc) return rc;
+        }
+    }
     // packed fast path: forward and sum-backward d_input, when the plan carries packed words, the relation
     // tile fits LDS and the gathered matrix is addressable with a 32-bit byte offset
     bool use_packed = false;
-    {
+    if (!use_rowgroup) {
         // forward gathers `input`; d_input gathers `output_grad`; d_relation gathers both (grad by node_b, input by node_a)
         const float *gather = (KIND == KIND_DX) ? p.grad : p.input;
         const unsigned long long gather_bytes = (unsigned long long)gather_rows * (unsigned long long)F * 4ull;
@@ -1179,7 +1255,7 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
             if (rc) return rc;
         }
     }
-    if (!use_packed) {
+    if (!use_packed && !use_rowgroup) {
         rc = launch_ops<KIND>(p, sum_op, mul_op, seg->weight == nullptr, rel_lds, grid,
                               kLdsHeader + (rel_lds ? lds_need : 0), stream);
         if (rc) return rc;
@@ -1247,6 +1323,7 @@ int ultra_rspmm_force_general_path(int on) {
     g_force_general = (on & 1) != 0;      // bit 0: general kernel instead of the packed one
     g_no_x_lds = (on & 2) != 0;           // bit 1: packed kernel without staging the gathered matrix in LDS
     g_no_quad = (on & 4) != 0;            // bit 2: one chunk per wave (packed_kernel) instead of four (quad_kernel)
+    g_no_rowgroup = (on & 8) != 0;        // bit 3: chunked kernels where one row per group (rowgroup_kernel) would run
     return ULTRA_OK;
 }
 
@@ -1294,6 +1371,42 @@ int ultra_rspmm_forward_f32(const ultra_segments *fwd, const float *relation, co
     p.out = out;
     return run_plan<KIND_FWD>(fwd, p, n_src, 0, n_rel, F, sum_op, mul_op, true, workspace, workspace_bytes,
                               static_cast<hipStream_t>(stream));
+}
+
+int ultra_rspmm_fwd_f32(const int32_t *row_ptr, const int32_t *src, const int32_t *rel, const float *w,
+                        const float *relation, const float *x, float *out, int64_t N, int64_t E, int64_t R, int64_t F,
+                        int sum_op, int mul_op, void *stream) {
+    if (N < 0 || E < 0 || R < 0 || F <= 0 || N > 0x7fffffffLL || E > 0x7fffffffLL || (F % 4) != 0) return ULTRA_ERR_BAD_SHAPE;
+    if (sum_op < 0 || sum_op > 2 || mul_op < 0 || mul_op > 1) return ULTRA_ERR_BAD_OP;
+    if (N == 0) return ULTRA_OK;
+    if (row_ptr == nullptr || out == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (E > 0 && (src == nullptr || rel == nullptr || relation == nullptr || x == nullptr)) return ULTRA_ERR_NULL_POINTER;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(relation)) & 15u)
+        return ULTRA_ERR_BAD_SHAPE;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo *di = nullptr;
+    int rc = device_info(dev, &di);
+    if (rc) return rc;
+    RowGroupParams q{};
+    q.row_ptr = row_ptr;
+    q.col = src;
+    q.rel = rel;
+    q.weight = w;
+    q.relation = relation;
+    q.gather = x;
+    q.out = out;
+    q.F = F;
+    q.n_rows = (int)N;
+    q.n_rel = (int)R;
+    q.n_tiles = (int)((F + kTile - 1) / kTile);
+    q.split = kXcd / gcd_int(q.n_tiles, kXcd);
+    q.n_slots = q.n_tiles * q.split;
+    q.blocks_per_label = (di->n_cu + kXcd - 1) / kXcd;
+    const size_t lds_need = (size_t)R * kTile * sizeof(float);
+    const bool rel_fits = R > 0 && lds_need <= (size_t)kMaxLdsBytes;
+    return launch_rowgroup(q, false, sum_op, mul_op, w == nullptr, rel_fits, q.blocks_per_label * kXcd,
+                           kLdsHeader + (rel_fits ? lds_need : 0), static_cast<hipStream_t>(stream));
 }
 
 int ultra_rspmm_forward_boundary_f32(const ultra_segments *fwd, const float *relation, const float *input,

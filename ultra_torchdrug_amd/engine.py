@@ -108,26 +108,29 @@ class GraphedPredict:
 
 
 class GraphedTrainStep:
-    """Forward + backward of one fine-tuning step (``ultra/engine.py:62-92``) for a fixed batch size as ONE hipGraph.
-    A step is ~800 launches, most of them tiny, and their host-side issue cost exceeds the GPU time of the kernels.
-    What has data-dependent shapes stays eager and feeds static buffers: the strict negatives (``nonzero`` over the
-    filter masks, task.py:102-118) and the mask of the batch's own edges (``graph.match``, model.py:57-74).  The
-    gradient all-reduce and the optimizer step follow the replay eagerly (``train_step`` semantics)."""
+    """One fine-tuning step (``ultra/engine.py:62-92``) for a fixed batch size as ONE hipGraph: strict negative
+    sampling, removal of the batch's own edges, forward and backward.  A step is ~800 launches, most of them tiny, and
+    their host-side issue cost exceeds the GPU time of the kernels.  Nothing in the step has a data-dependent shape any
+    more: the negatives come from the sorted completion keys (``ultra_strict_negative``) and the edge removal from a
+    binary search in the plans (``ultra_edge_removal_weights``), where the reference builds ``(B / 2, N)`` masks,
+    calls ``nonzero`` and re-sorts a new graph (task.py:102-118, model.py:57-74).  The gradient all-reduce and the
+    optimizer step follow the replay eagerly (``train_step`` semantics).  Models the native removal does not cover
+    (min / max / PNA aggregation, ``remove_one_hop``) keep eager steps: use :func:`train_step`."""
 
-    def __init__(self, task, optimizer, example_batch, warmup=3):
+    def __init__(self, task, optimizer, example_batch, warmup=3, reducer=None):
         assert example_batch.is_cuda and task.training
-        self.task, self.optimizer = task, optimizer
         model = task.model
+        if model.remove_one_hop or not model._removal_by_zero_weight(sums_only=True):
+            raise ValueError("GraphedTrainStep needs summed messages and remove_one_hop=False (the edge removal that can "
+                             "be captured); use engine.train_step for this model")
+        self.task, self.optimizer, self.reducer = task, optimizer, reducer
         self.static_batch = example_batch.clone()
-        self.static_neg, self.static_keep = self._eager_inputs(self.static_batch)
-        self.static_neg, self.static_keep = self.static_neg.clone(), self.static_keep.clone()
         model.check_indices = False
-        task._static_negative, model._static_keep = self.static_neg, self.static_keep
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(warmup):             # plans, kernel attributes, workspaces, allocator
+                for _ in range(warmup):             # plans, completion keys, kernel attributes, workspaces, allocator
                     optimizer.zero_grad(set_to_none=True)
                     loss, _ = task(self.static_batch)
                     loss.backward()
@@ -137,28 +140,19 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
                 self.static_loss, self.static_metric = task(self.static_batch)
                 self.static_loss.backward()
+            self.last_negatives = task.last_negatives       # (B, num_negative): rewritten by every replay
         finally:
             model.check_indices = True
-            task._static_negative, model._static_keep = None, None
-
-    def _eager_inputs(self, batch):
-        task, model = self.task, self.task.model
-        task._static_negative, model._static_keep = None, None
-        h_index, t_index, r_index = task.training_indices(batch)
-        keep = model.easy_edge_mask(task.fact_graph, h_index, t_index, r_index)
-        half = len(batch) // 2
-        neg = torch.cat([t_index[:half, 1:], h_index[half:, 1:]])
-        return neg, keep
 
     def __call__(self, batch):
         """One step on ``batch`` (same shape as the example): returns ``(loss, metrics averaged over ranks)``."""
         assert batch.shape == self.static_batch.shape
-        neg, keep = self._eager_inputs(batch)
         self.static_batch.copy_(batch)
-        self.static_neg.copy_(neg)
-        self.static_keep.copy_(keep)
         self.graph.replay()
-        allreduce_gradients(self.task)
+        if self.reducer is not None:
+            self.reducer.reduce_all()
+        else:
+            allreduce_gradients(self.task)
         self.optimizer.step()
         return self.static_loss.detach(), reduce_metrics(self.static_metric)
 
@@ -216,6 +210,131 @@ def allreduce_gradients(module, average=True):
     return flat.numel()
 
 
+# parameters of the shipped architecture that never receive a gradient (the reference needs
+# find_unused_parameters=True for them, ultra/engine.py:55-60): `dist_embed` is never used in forward
+# (ultra/model.py:55) and the relation model's `mlp` is constructed but not called (ultra/rel_model.py:263,376-378)
+UNUSED_PARAMETER_MARKS = ("model.dist_embed.", ".model.mlp.")
+
+
+class GradientReducer:
+    """Bucketed gradient all-reduce that overlaps the backward pass (what DDP does for the reference,
+    ``ultra/engine.py:55-60``; BASELINE north star: "overlapped with the next layer's rspmm on a side HIP stream").
+
+    Buckets follow the order in which backward produces gradients: the score head first, then the entity layers last to
+    first, then the relation-model layers last to first -- one bucket per layer (a layer's parameters become ready
+    together, right after its rspmm backward).  A ``post_accumulate_grad`` hook per parameter counts a bucket down; when
+    the last gradient of a bucket exists the bucket is packed on the compute stream, and its all-reduce is enqueued on a
+    SIDE stream (RCCL runs it there while the compute stream continues with the next layer's rspmm backward).  Buckets
+    are always launched in bucket order, so every rank issues the same sequence of collectives even when ranks train on
+    different graphs (multi-graph pre-training, ``ultra/engine.py:23-34``).  ``finish()`` makes the compute stream wait
+    for the side stream and unpacks the averaged gradients; it must run before ``optimizer.step()``.
+    Parameters that never receive a gradient (``UNUSED_PARAMETER_MARKS``) are excluded statically."""
+
+    def __init__(self, module, average=True, overlap=True):
+        self.module, self.average, self.overlap = module, average, overlap
+        named = [(k, p) for k, p in module.named_parameters()
+                 if p.requires_grad and not any(mark in k for mark in UNUSED_PARAMETER_MARKS)]
+
+        def bucket_key(name):
+            parts = name.split(".")
+            if "layers" in parts and not name.startswith("model.mlp"):
+                i = parts.index("layers")
+                stack = 0 if parts[0] == "model" else 1
+                return (1 + stack, -int(parts[i + 1]), ".".join(parts[:i + 2]))
+            return (0, 0, parts[0] + "." + parts[1] if len(parts) > 1 else parts[0])      # score head, query embeddings
+
+        groups = {}
+        for name, p in named:
+            groups.setdefault(bucket_key(name), []).append((name, p))
+        self.buckets = []
+        for key in sorted(groups):
+            params = [p for _, p in groups[key]]
+            self.buckets.append({"name": key[2], "params": params, "names": [n for n, _ in groups[key]],
+                                 "numel": sum(p.numel() for p in params), "flat": None, "work": None})
+        self._bucket_of = {}
+        for b, bucket in enumerate(self.buckets):
+            for p in bucket["params"]:
+                self._bucket_of[id(p)] = b
+        self._side = None
+        self._handles = []
+        self._reset()
+        if overlap:
+            for bucket in self.buckets:
+                for p in bucket["params"]:
+                    self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _reset(self):
+        self._pending = [len(b["params"]) for b in self.buckets]
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
+        self._launched = 0
+
+    def remove_hooks(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    # ------------------------------------------------------------------ hooks (autograd thread, during backward)
+    def _on_grad(self, param):
+        if get_world_size() == 1:
+            return
+        b = self._bucket_of[id(param)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._ready[b] = True
+            while self._next < len(self.buckets) and self._ready[self._next]:
+                self._launch(self._next)
+                self._next += 1
+
+    def _launch(self, b):
+        bucket = self.buckets[b]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket["params"]]
+        flat = torch.cat([g.reshape(-1) for g in grads])                    # packed on the compute stream
+        bucket["flat"] = flat
+        if flat.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=flat.device)
+            self._side.wait_stream(torch.cuda.current_stream(flat.device))   # the pack must be complete
+            with torch.cuda.stream(self._side):
+                bucket["work"] = dist.all_reduce(flat, async_op=True)        # RCCL, enqueued behind the side stream
+            flat.record_stream(self._side)
+        else:
+            bucket["work"] = dist.all_reduce(flat, async_op=True)
+        self._launched += 1
+
+    # ------------------------------------------------------------------ after backward, before optimizer.step()
+    def finish(self):
+        """Wait for every bucket (launching those whose hooks did not fire: ``overlap=False`` or a graph replay) and
+        write the reduced gradients back.  Returns the number of fp32 elements reduced."""
+        world = get_world_size()
+        if world == 1:
+            self._reset()
+            return 0
+        while self._next < len(self.buckets):                               # in bucket order, on every rank
+            self._launch(self._next)
+            self._next += 1
+        total = 0
+        for bucket in self.buckets:
+            bucket["work"].wait()                                           # compute stream waits for the collective
+            flat = bucket["flat"]
+            if self.average:
+                flat /= world
+            offset = 0
+            for p in bucket["params"]:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = flat[offset:offset + n].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[offset:offset + n].view_as(p.grad))
+                offset += n
+            total += flat.numel()
+            bucket["flat"] = bucket["work"] = None
+        self._reset()
+        return total
+
+    reduce_all = finish
+
+
 def reduce_metrics(metric):
     """Mean over ranks of a dict of 0-d tensors, in one packed all-reduce (``ultra/engine.py:90``)."""
     world = get_world_size()
@@ -228,12 +347,17 @@ def reduce_metrics(metric):
     return {k: packed[i] for i, k in enumerate(keys)}
 
 
-def train_step(task, optimizer, batch):
+def train_step(task, optimizer, batch, reducer=None):
     """One fine-tuning step (``ultra/engine.py:62-92`` / torchdrug ``Engine.train``): forward, backward,
-    gradient all-reduce, optimizer step.  Returns (loss, metrics averaged over ranks)."""
+    gradient all-reduce, optimizer step.  Returns (loss, metrics averaged over ranks).  ``reducer``: a
+    :class:`GradientReducer` over ``task`` -- its hooks start each layer's all-reduce on a side stream while backward
+    is still running; without one the gradients go through one flat blocking all-reduce after backward."""
     loss, metric = task(batch)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
-    allreduce_gradients(task)
+    if reducer is not None:
+        reducer.finish()
+    else:
+        allreduce_gradients(task)
     optimizer.step()
     return loss.detach(), reduce_metrics(metric)

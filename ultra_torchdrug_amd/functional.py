@@ -132,6 +132,38 @@ def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, bou
     return out
 
 
+def rspmm_forward_csr(row_ptr, src, rel, weight, relation, input, sum="add", mul="mul"):
+    """The operator straight from a coalesced CSR (``ultra_rspmm_fwd_f32``, SURVEY.md 8b's raw entry): ``row_ptr`` int32
+    ``(N + 1,)``, ``src`` / ``rel`` int32 ``(E,)`` sorted by (row, src, rel), ``weight`` fp32 ``(E,)`` or ``None``.
+    No plan and no workspace; every row is reduced strictly sequentially (the reference order).  Forward only."""
+    sum_op, mul_op = _ops(sum, mul)
+    if input.dim() != 2 or relation.dim() != 2 or relation.shape[1] != input.shape[1]:
+        raise RuntimeError("relation (R, F) and input (N_src, F) expected, got %s and %s"
+                           % (tuple(relation.shape), tuple(input.shape)))
+    tensors = [row_ptr, src, rel, relation, input] + ([weight] if weight is not None else [])
+    if any(not t.is_cuda or t.device != input.device for t in tensors):
+        raise RuntimeError("rspmm_forward_csr runs on an MI355X (HIP) device only. There is no CPU fallback.")
+    if row_ptr.dtype != torch.int32 or src.dtype != torch.int32 or rel.dtype != torch.int32:
+        raise RuntimeError("rspmm_forward_csr: row_ptr / src / rel must be int32")
+    if input.dtype != torch.float32 or relation.dtype != torch.float32 or (weight is not None and weight.dtype != torch.float32):
+        raise RuntimeError("rspmm is fp32 only (TF32 is disabled in the reference, script/run_full.py:19-20)")
+    F = input.shape[1]
+    if F % 4:
+        raise RuntimeError("rspmm_forward_csr needs 16-byte rows (F % 4 == 0); use a RelCSR plan for other widths")
+    n_rows, n_edges = row_ptr.numel() - 1, src.numel()
+    relation, input = relation.contiguous(), input.contiguous()
+    out = torch.empty(n_rows, F, dtype=torch.float32, device=input.device)
+    if out.numel() == 0:
+        return out
+    lib = _lib.load()
+    with torch.cuda.device(input.device):
+        _lib.check(lib.ultra_rspmm_fwd_f32(
+            row_ptr.contiguous().data_ptr(), src.contiguous().data_ptr(), rel.contiguous().data_ptr(),
+            weight.contiguous().data_ptr() if weight is not None else None, relation.data_ptr(), input.data_ptr(),
+            out.data_ptr(), n_rows, n_edges, relation.shape[0], F, sum_op, mul_op, _stream()))
+    return out
+
+
 def frontier_supported(sum, mul, F):
     """The first-layer shortcut holds where a zero source row contributes exactly +-0: summed DistMult messages."""
     return sum == "add" and mul == "mul" and F % 64 == 0

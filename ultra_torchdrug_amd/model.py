@@ -53,9 +53,6 @@ class TransferNBFNet(nn.Module):
     def easy_edge_mask(self, graph, h_index, t_index, r_index=None):
         """model.py:57-73: True for the edges that stay -- every edge except the batch's own positives (and their
         reverse when ``remove_one_hop``)."""
-        static = getattr(self, "_static_keep", None)
-        if static is not None:          # engine.GraphedTrainStep: computed eagerly, the captured step reads this buffer
-            return static
         if self.remove_one_hop:
             h_ext = torch.cat([h_index, t_index], dim=-1)
             t_ext = torch.cat([t_index, h_index], dim=-1)
@@ -193,7 +190,7 @@ class TransferNBFNet(nn.Module):
             # builds (and torchdrug re-sorts) a new graph every step; here the cached plans of the full graph are
             # reused and the removed edges get weight 0 for this step -- identical sums, no sort.
             if (graph.num_relation and r_index is not None and not self.remove_one_hop
-                    and self._removal_by_zero_weight(sums_only=True) and getattr(self, "_static_keep", None) is None):
+                    and self._removal_by_zero_weight(sums_only=True)):
                 # one native call on the graph with inverse edges (below): no match(), no host synchronisation
                 removal = (h_index, t_index, r_index)
             else:

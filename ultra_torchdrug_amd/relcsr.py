@@ -78,11 +78,13 @@ class Segments:
         n_a = int(n_node_a) if n_node_a is not None else (int(node_a.max()) + 1 if n_edges else 1)
         self.hot_nodes, self.n_hot = None, 0
         self.packed, self.packed_src_shift = None, 0
+        self.row_ptr = None
         if builder is None:
             builder = os.environ.get("ULTRA_RELCSR_BUILDER") or ("native" if row.is_cuda else "torch")
         self.builder = "torch" if (hot_cache or not row.is_cuda) else builder
         if self.builder == "native":
             self._build_native(n_a, n_rel, chunk_edges, chunk_rows, piece_len, balance, wide_ids)
+            self._build_row_ptr()
             self.struct = _lib.UltraSegments()
             self._refresh_struct()
             return
@@ -134,6 +136,7 @@ class Segments:
             self.node_a = torch.cat([self.node_a, torch.zeros(PACK_SLACK, dtype=i32, device=dev)]).contiguous()
         self.long_rows = long_rows.to(i32).contiguous()
         self.n_pieces = int(n_pieces)
+        self._build_row_ptr()
 
         self.struct = _lib.UltraSegments()
         self._refresh_struct()
@@ -166,6 +169,13 @@ class Segments:
             if shift == 32:     # node ids are read from node_a in whole batches: same slack as the packed words
                 self.node_a = torch.cat([self.node_a, torch.zeros(PACK_SLACK, dtype=i32, device=dev)]).contiguous()
 
+    def _build_row_ptr(self):
+        """Row pointers for the plans of big graphs (node ids outside the packed word): with them and no split rows the
+        library reduces one row per 16-lane group (csrc/rowgroup.inc) instead of walking chunks."""
+        if self.packed_src_shift == 32 and self.n_edges:
+            rows = torch.arange(self.n_rows + 1, dtype=torch.int32, device=self.row.device)
+            self.row_ptr = torch.searchsorted(self.row, rows).to(torch.int32).contiguous()
+
     def _refresh_struct(self):
         s = self.struct
         s.n_rows, s.n_edges = self.n_rows, self.n_edges
@@ -184,6 +194,7 @@ class Segments:
         s.packed_src_shift = self.packed_src_shift
         s.n_hot = self.n_hot
         s.hot_nodes = self.hot_nodes.data_ptr() if self.hot_nodes is not None else None
+        s.row_ptr = self.row_ptr.data_ptr() if self.row_ptr is not None else None
 
     @property
     def pointer(self):

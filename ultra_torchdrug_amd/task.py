@@ -292,6 +292,7 @@ class KnowledgeGraphCompletion(nn.Module):
         pos_h_index, pos_t_index, pos_r_index = batch.t()
         batch_size = len(batch)
         neg_index = self._strict_negative(pos_h_index, pos_t_index, pos_r_index)
+        self.last_negatives = neg_index
         h_index = pos_h_index.unsqueeze(-1).repeat(1, self.num_negative + 1)
         t_index = pos_t_index.unsqueeze(-1).repeat(1, self.num_negative + 1)
         r_index = pos_r_index.unsqueeze(-1).repeat(1, self.num_negative + 1)
