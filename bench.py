@@ -8,17 +8,26 @@ synthetic KG of FB15k237's size (N=14 541, 272 115 triples, 237 relations => E=5
 edges), seeded random-init Ultra weights (6 x 64d entity stack + 6 x 64d relation stack).
 One STEP = one evaluation batch of B=16 test triples through ``predict`` (/root/reference/ultra/task.py:228-263):
 relation-graph Bellman-Ford (6 rspmm) + tail pass + head pass over all N candidates (the reference: 2 x 6 rspmm +
-epilogues + score MLP = 18 rspmm calls; here the tail and head queries share ONE 2B-wide Bellman-Ford, 6 launches of
-twice the width, every score bit-identical: tests/test_model_gpu.py) -- exactly the reference's unit of evaluation
-work.  Unit of work = one edge message = one edge x one batch element x 64 fp32 lanes; a step aggregates
-12*E*B + 6*E_rel*B of them.  All inputs are
-resident in HBM before the timed region.  Multi-GPU: every rank holds the graph and evaluates its own query
-batch (query sharding, no data-path collective) => weak scaling.
+epilogues + score MLP = 18 rspmm calls; here the tail and head queries share ONE 2B-wide Bellman-Ford, every score
+bit-identical: tests/test_model_gpu.py), replayed as one hipGraph.  Unit of work = one edge message = one edge x one
+batch element x 64 fp32 lanes; a step aggregates 12*E*B + 6*E_rel*B of them (sum of nnz * B over all
+rspmm calls).  All inputs are resident in HBM before the timed region.  Multi-GPU: every rank holds the graph and
+evaluates its own query batch (query sharding, no data-path collective) => weak scaling.
 
-Also reported on the same line: ``roofline`` for the dominant kernel (entity-graph rspmm forward; HIP events
-recorded around exactly that kernel on its stream, inside the timed region) and ``cpu_baseline`` (the CPU oracle's
-row loop -- a restatement of the torchdrug CPU algorithm, kind "port" -- timed on this box's host cores on one
-rspmm call of the same graph).
+Reported beside ``value`` on the same line (every fraction can be recomputed from the numbers printed with it and
+from profiles/):
+* ``composition``      -- entity-graph and relation-graph edge messages per step and the entity-only rate; the step
+                          with and without the first-layer frontier shortcut; predict + filtered ranking per step.
+* ``roofline``         -- the dominant kernel of THIS workload (entity-graph forward, quad_kernel).  Its gathered
+                          matrix (119 MB) lives in L2 / Infinity Cache, so it is priced as what it is, an L2-gather
+                          kernel: algorithmic bytes per launch / launch time against the XCD-L2 peak (34.5 TB/s) and
+                          the guide's measured ceiling for rows gathered from L2 (16.8-18.8 TB/s), plus the HBM
+                          fraction on COMPULSORY bytes.  HIP events around exactly that kernel, on its stream.
+* ``roofline_hbm``     -- config 5 (S-stress, 10 M nodes / 100 M edges / 1 k relations, B = 1) AT SIZE: the
+                          DRAM-bound regime, algorithmic bytes against the 8 TB/s HBM peak ("S-stress
+                          is the roofline reference").
+* ``cpu_baseline``     -- the CPU oracle's row loop (restatement of the torchdrug CPU algorithm, kind "port") on all
+                          host cores, one rspmm call of the bench graph.
 """
 import argparse
 import ctypes
@@ -35,7 +44,10 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+# MI355X_MICROARCH.md: chip-level parameters / L2 (per XCD) / Indexed rows: gather into LDS
+HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0
+L2_GATHER_CEILING_GBS = (16800.0, 18800.0)
 
 
 class HipEvents:
@@ -69,10 +81,27 @@ def bytes_algo(E, N, R, F):
     return E * (4 * F + 12) + 4 * N * F + 4 * R * F + 4 * (N + 1)
 
 
+def bytes_min(E, N, R, F):
+    """SURVEY.md 8d, compulsory bytes (perfect reuse): input read once, output written once, indices, relation table."""
+    return 8 * N * F + 4 * R * F + 12 * E + 4 * (N + 1)
+
+
+def timed_kernel(lib, events, fn, n):
+    """Average duration (ms) of the main rspmm kernel inside `fn`, from HIP events recorded by the library around it."""
+    first = len(events.pairs)
+    for _ in range(n):
+        a, b = events.new_pair()
+        lib.ultra_rspmm_profile_next(a, b)
+        fn()
+    torch.cuda.synchronize()
+    ms = events.elapsed_ms()[first:]
+    return float(np.mean(ms)), len(ms)
+
+
 def cpu_baseline(graph_np, n_node, n_rel, F, budget_s=20.0):
     """The oracle's CSR row loop (OpenMP over rows) on ONE rspmm call of the bench graph; rank 0, N=1 only."""
     from oracle import oracle as O
-    threads = min(len(os.sched_getaffinity(0)), 16)
+    threads = len(os.sched_getaffinity(0))           # all host cores this process may use
     os.environ["OMP_NUM_THREADS"] = str(threads)
     O.build()
     rng = np.random.default_rng(1024)
@@ -103,47 +132,58 @@ def cpu_baseline(graph_np, n_node, n_rel, F, budget_s=20.0):
                       % (len(times), csr.n_edges, F, F // 64, med)}
 
 
-def dram_probe(dev, lib, n_node=4_000_000, n_edge=40_000_000, n_rel=1000):
-    """The same forward kernel family on a graph whose input (1 GB at B = 1) cannot live in the 256 MB Infinity Cache:
-    uniform random edges, F = 64 -- a scaled-down S-stress (config 5), so that one line of the bench carries a
-    DRAM-bound roofline fraction next to the cache-resident headline workload."""
+def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel=500):
+    """Config 5 at size: S-stress -- uniform triples + inverse edges => E = 100 M, R = 1 000, 64d,
+    B = 1.  The gathered matrix (2.56 GB) cannot live in any cache: the HBM roofline of the operator."""
     import ultra_torchdrug_amd as U
     from ultra_torchdrug_amd import functional as UF
     gen = torch.Generator(device=dev).manual_seed(1024)
-    dst = torch.randint(0, n_node, (n_edge,), device=dev, generator=gen)
-    src = torch.randint(0, n_node, (n_edge,), device=dev, generator=gen)
-    rel = torch.randint(0, n_rel, (n_edge,), device=dev, generator=gen)
-    csr = U.RelCSR(dst, src, rel, None, n_node, n_node, n_rel)
-    del dst, src, rel
-    F = 64
+    h = torch.randint(0, n_node, (n_triple,), device=dev, generator=gen)
+    t = torch.randint(0, n_node, (n_triple,), device=dev, generator=gen)
+    r = torch.randint(0, n_base_rel, (n_triple,), device=dev, generator=gen)
+    t0 = time.perf_counter()
+    csr = U.RelCSR(torch.cat([t, h]), torch.cat([h, t]), torch.cat([r, r + n_base_rel]), None, n_node, n_node,
+                   2 * n_base_rel)
+    plan = csr.fwd
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    del h, t, r
+    F, R = 64, 2 * n_base_rel
     x = torch.randn(n_node, F, device=dev, generator=gen)
-    relation = torch.randn(n_rel, F, device=dev, generator=gen)
+    relation = torch.randn(R, F, device=dev, generator=gen)
     for _ in range(3):
         UF.rspmm_forward(csr, relation, x, "add", "mul")
     events = HipEvents(lib)
-    for _ in range(10):
-        a, b = events.new_pair()
-        lib.ultra_rspmm_profile_next(a, b)
-        UF.rspmm_forward(csr, relation, x, "add", "mul")
-    torch.cuda.synchronize()
-    ms = float(np.median(events.elapsed_ms()))
+    ms, n = timed_kernel(lib, events, lambda: UF.rspmm_forward(csr, relation, x, "add", "mul"), 12)
+    # the chunked kernel the plan would run without the row-per-group kernel (A/B of the same launch)
+    lib.ultra_rspmm_force_general_path(8)
+    try:
+        for _ in range(2):
+            UF.rspmm_forward(csr, relation, x, "add", "mul")
+        ms_chunked, _ = timed_kernel(lib, events, lambda: UF.rspmm_forward(csr, relation, x, "add", "mul"), 6)
+    finally:
+        lib.ultra_rspmm_force_general_path(0)
     E = csr.n_edges
-    algo = bytes_algo(E, n_node, n_rel, F)
-    return {"workload": "uniform random N=%d E=%d R=%d B=1 F=64 (input %.1f GB > Infinity Cache)" % (n_node, E, n_rel, n_node * F * 4 / 1e9),
-            "kernel_ms": ms, "bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "edges_per_s": E / (ms * 1e-3)}
+    algo = bytes_algo(E, n_node, R, F)
+    kernel = "rowgroup_kernel<add,mul,unit_w,rel via L2>" if plan.row_ptr is not None and plan.n_pieces == 0 \
+        else "packed_kernel<FWD,add,mul,unit_w,VAR 2>"
+    return {"bound": "hbm", "workload": "S-stress N=%d E=%d R=%d B=1 F=64 (input %.2f GB)" % (n_node, E, R, n_node * F * 4 / 1e9),
+            "kernel": kernel, "launches_timed": n, "kernel_ms": ms, "algorithmic_bytes": algo,
+            "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "edges_per_s": E / (ms * 1e-3), "chunked_kernel_ms": ms_chunked, "plan_build_s": build_s}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16, help="queries per step (reference inference batch: 16)")
     ap.add_argument("--workload", default="S-fb15k237")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dram-probe", dest="dram_probe", action="store_false",
-                    help="skip the DRAM-bound probe (4M nodes / 40M edges, ~5 s) reported as roofline_dram_probe")
+    ap.add_argument("--no-stress", dest="stress", action="store_false",
+                    help="skip config 5 at size (S-stress: 10 M nodes / 100 M edges, ~15 s) reported as roofline_hbm")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--mrr-queries", type=int, default=64, help="seeded test triples ranked after the timed region")
     ap.add_argument("--finetune-steps", type=int, default=50, help="seeded fine-tuning steps before the second MRR")
@@ -152,25 +192,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # ULTRA_BENCH_SHARE_GPU=1 (development only): all ranks on the visible GPU(s), gloo instead of RCCL -- lets the
     # multi-rank code path (sharding, barriers, max-over-ranks timing) run on a one-GPU box
     share = os.environ.get("ULTRA_BENCH_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count()              # (does not initialise the GPU)
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if share:
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        local_rank %= n_dev
+    # the process group comes first: RCCL is initialised before this process makes any other GPU call
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
         if share:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     assert world == args.gpus or world == 1, "launch N ranks with torch.distributed.run for --gpus N"
 
     import ultra_torchdrug_amd as U
-    from ultra_torchdrug_amd import _lib
+    from ultra_torchdrug_amd import layer as UL
     from ultra_torchdrug_amd.data import synthetic_triples, DEFAULT_SEED
     from ultra_torchdrug_amd.graph import Graph
     from ultra_torchdrug_amd.task import build_ultra
@@ -206,12 +250,17 @@ def main():
     E_rel = task.rel_graphs[0].relcsr.n_edges
     for g in (und, task.rel_graphs[0]):
         _ = g.relcsr.fwd                                      # plans built before the timed region
+        _ = g.relcsr.frontier_index
+    for g in (task.graph, task.fact_graph):
+        g.completion_keys(0), g.completion_keys(1)            # sorted filter keys: once per graph
     B = args.batch
     F = B * 64
     # predict() scores tails and heads in ONE Bellman-Ford over 2B queries (task.fuse_sides): 6 entity launches of
     # width 2F per step instead of 12 of width F -- the same edge messages
     Fk = 2 * F
-    edges_per_step = (12 * E + 6 * E_rel) * B
+    entity_edges_per_step = 12 * E * B
+    rel_edges_per_step = 6 * E_rel * B
+    edges_per_step = entity_edges_per_step + rel_edges_per_step
 
     # each rank evaluates its own strided shard of the seeded test triples (DistributedSampler-style)
     test = torch.from_numpy(triples[test_idx]).to(dev)
@@ -220,8 +269,8 @@ def main():
 
     # profile hook: HIP events around the entity-graph forward kernel (the dominant kernel), recorded by the library
     # on the kernel's own stream.  --eager: one pair per launch of the timed region.  Default (hipGraph replay): event
-    # records cannot be captured with the HIP runtime PyTorch bundles, so the same kernel is launched 24 more times
-    # eagerly, with the step's own shapes and fused boundary add, right after the timed region and timed there.
+    # records cannot be captured with the HIP runtime PyTorch bundles, so the same kernel is launched eagerly, with the
+    # step's own shapes and fused boundary epilogue, right after the timed region and timed there.
     events = HipEvents(lib)
     from ultra_torchdrug_amd import functional as UF
     real_forward = UF.rspmm_forward
@@ -237,20 +286,31 @@ def main():
 
     # the evaluation batch is replayed as one hipGraph (engine.GraphedPredict); --eager times the un-captured path
     from ultra_torchdrug_amd.engine import GraphedPredict
-    graphed = None
-    if not args.eager:
+
+    def capture():
         with torch.no_grad():
             task.predict(shard[:B])                 # plans, kernel attributes, allocator: before the capture
         try:
-            graphed = GraphedPredict(task, shard[:B], warmup=0)
+            return GraphedPredict(task, shard[:B], warmup=0)
         except Exception as err:                    # capture refused (driver / runtime): time the eager path
             print("bench: hipGraph capture failed (%s); falling back to eager launches" % err, file=sys.stderr)
             torch.cuda.synchronize()
-            graphed = None
+            return None
 
-    def step(i):
+    graphed = None if args.eager else capture()
+
+    def step(i, g=None):
+        g = graphed if g is None else g
         batch = shard[(i % n_batches) * B:(i % n_batches) * B + B]
-        return task.predict(batch) if graphed is None else graphed(batch)
+        return task.predict(batch) if g is None else g(batch)
+
+    def time_steps(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
 
     with torch.no_grad():
         for i in range(args.warmup):
@@ -269,27 +329,37 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         state["on"] = False
-        if graphed is not None:     # dominant kernel, eager, same stream / shapes / fused epilogue as inside the step
-            gen = torch.Generator(device=dev).manual_seed(DEFAULT_SEED)
-            xk = torch.randn(n_node, Fk, device=dev, generator=gen)
-            rk = torch.randn(R2, Fk, device=dev, generator=gen)
-            bk = (torch.randint(0, n_node, (Fk // 64,), device=dev, generator=gen).to(torch.int32),
-                  torch.randn(Fk // 64, 64, device=dev, generator=gen))            # the layer's sparse boundary
+
+        # ---- after the timed region: the dominant kernel alone, and the other per-step numbers
+        gen = torch.Generator(device=dev).manual_seed(DEFAULT_SEED)
+        xk = torch.randn(n_node, Fk, device=dev, generator=gen)
+        rk = torch.randn(R2, Fk, device=dev, generator=gen)
+        bk = (torch.randint(0, n_node, (Fk // 64,), device=dev, generator=gen).to(torch.int32),
+              torch.randn(Fk // 64, 64, device=dev, generator=gen))            # the layer's sparse boundary
+        if graphed is not None:
             for _ in range(4):
                 real_forward(und.relcsr, rk, xk, "add", "mul", None, bk)
             state["on"] = True
-            for _ in range(24):
+            for _ in range(48):
                 timed_forward(und.relcsr, rk, xk, "add", "mul", None, bk)
             state["on"] = False
             torch.cuda.synchronize()
-            # un-captured step time, for reference
-            t1 = time.perf_counter()
+        kernel_ms = events.elapsed_ms()
+        n_side = min(args.steps, 50)
+        eager_ms = time_steps(lambda i: task.predict(shard[:B]), 5) if graphed is not None else 1e3 * elapsed / args.steps
+        # predict + filtered ranking (what engine.evaluate does per batch): the ranks come from the sorted completion keys
+        # on the device, nothing but (B, 2) int64 leaves it
+        rank_ms = time_steps(lambda i: task.rank_batch(shard[:B], pred=step(i)), n_side)
+        # the same step without the first-layer frontier shortcut (every layer walks all E edges)
+        UL.FRONTIER_FIRST_LAYER = False
+        try:
+            plain = None if args.eager else capture()
             for i in range(5):
-                task.predict(shard[:B])
-            torch.cuda.synchronize()
-            eager_ms = 1e3 * (time.perf_counter() - t1) / 5
-        else:
-            eager_ms = 1e3 * elapsed / args.steps
+                step(i, plain)
+            no_frontier_ms = time_steps(lambda i: step(i, plain), n_side)
+        finally:
+            UL.FRONTIER_FIRST_LAYER = True
+        frontier_ms, _ = timed_kernel(lib, events, lambda: UF.rspmm_frontier(und.relcsr, rk, bk), 10)
     UF.rspmm_forward = real_forward
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
@@ -297,17 +367,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # HBM bytes per launch of the dominant kernel, from the committed PMC passes of the same kernel and workload
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_fwd_fb15k237.json")
-    if args.workload == "S-fb15k237" and args.batch == 16 and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("F") == Fk:
-            traffic = tj.get("hbm_bytes_per_launch")
+    # fabric bytes per launch of the dominant kernel: separate rocprofv3 --pmc passes of the same kernel and workload
+    # (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction), committed under profiles/ -- not measured in this run
+    traffic, traffic_source = None, None
+    for name in ("r02_traffic_fwd_fb15k237.json", "traffic_fwd_fb15k237.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if args.workload == "S-fb15k237" and args.batch == 16 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("F") == Fk:
+                traffic, traffic_source = tj.get("hbm_bytes_per_launch"), "profiles/%s (rocprofv3 --pmc passes, not this run)" % name
+                break
 
-    kernel_ms = events.elapsed_ms()
     k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     algo = bytes_algo(E, n_node, R2, Fk)
+    compulsory = bytes_min(E, n_node, R2, Fk)
+    achieved = algo / (k_avg_ms * 1e-3) / 1e9
 
     # ---------------- MRR (after the timed region): HIP path, and HIP vs CPU-oracle path on the same weights --------
     def mrr_of(t, queries):
@@ -329,7 +403,7 @@ def main():
             ranks_cpu = cpu_task.get_ranking(pred_cpu, cpu_task.target(batch_cpu))
         with torch.no_grad():
             pred_gpu = task.predict(shard[:B])
-            ranks_gpu = task.get_ranking(pred_gpu, task.target(shard[:B])).cpu()
+            ranks_gpu = task.rank_batch(shard[:B], pred=pred_gpu).cpu()
         return {"weights": label, "queries": int(B), "mrr_hip": float((1.0 / ranks_gpu.float()).mean()),
                 "mrr_cpu_oracle": float((1.0 / ranks_cpu.float()).mean()),
                 "ranks_identical": int((ranks_gpu == ranks_cpu).sum()), "ranks_total": int(ranks_cpu.numel()),
@@ -337,6 +411,7 @@ def main():
 
     mrr = mrr_tuned = None
     mrr_check = []
+    train_ms = None
     if args.mrr_queries > 0:
         nq = min(args.mrr_queries, len(shard))
         mrr = float((1.0 / mrr_of(task, shard[:nq]).float()).mean())
@@ -352,21 +427,26 @@ def main():
             facts = torch.from_numpy(triples[:n_fact]).to(dev)
             pick = np.random.default_rng(DEFAULT_SEED)
             torch.manual_seed(DEFAULT_SEED)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
             for _ in range(args.finetune_steps):
                 idx = torch.from_numpy(pick.choice(n_fact, B, replace=False)).to(dev)
                 engine.train_step(task, opt, facts[idx])
+            torch.cuda.synchronize()
+            train_ms = 1e3 * (time.perf_counter() - t1) / args.finetune_steps
             task.eval()
             mrr_tuned = float((1.0 / mrr_of(task, shard[:nq]).float()).mean())
             if check:
                 mrr_check.append(oracle_check("after %d seeded fine-tuning steps on the HIP path" % args.finetune_steps))
 
     if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
         result = {
             "metric": "edges aggregated/sec, FB15k237-shaped 6L x 64d rspmm Bellman-Ford (predict: 18 rspmm/batch)",
             "value": edges_per_step * args.steps * world / elapsed,
             "unit": "edges aggregated/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s N=%d E=%d R=%d B=%d F=%d, 6+6 layers x 64d, predict() tail+head over all "
@@ -374,18 +454,45 @@ def main():
                        "global_batch": B * world, "parallelism": "query-sharded replicas x%d" % world,
                        "launch": "eager" if graphed is None else "one hipGraph replay per step (engine.GraphedPredict)"},
             "edges_per_step": edges_per_step,
+            "composition": {
+                "entity_graph_edges_per_step": entity_edges_per_step,
+                "relation_graph_edges_per_step": rel_edges_per_step,
+                "relation_graph_note": "E_rel = %d over %d relation nodes and 4 edge types: with independently drawn Zipf "
+                                       "heads / tails / relations (SURVEY 8d generator) every pair of relations co-occurs, "
+                                       "so the relation graph is complete -- LDS-resident, not a sparse-gather workload"
+                                       % (E_rel, R2),
+                "value_entity_only": entity_edges_per_step * args.steps * world / elapsed,
+                "ms_per_step_without_first_layer_frontier": no_frontier_ms,
+                "value_without_first_layer_frontier": edges_per_step * world / (no_frontier_ms * 1e-3),
+                "first_layer_frontier_kernel_ms": frontier_ms,
+                "first_layer_note": "layer 1 reads the boundary (zero outside one row per query): its E * B edge messages are "
+                                    "+-0 except on the out-edges of the boundary nodes; the frontier kernel adds exactly "
+                                    "those, bit-identically (tests/test_frontier_sampler_gpu.py); `value` counts the "
+                                    "layer's edges as aggregated either way",
+                "predict_plus_filtered_rank_ms_per_step": rank_ms,
+                "value_predict_plus_rank": edges_per_step * world / (rank_ms * 1e-3),
+                "finetune_ms_per_step_eager": train_ms,
+            },
             "plan_build_ms": plan_build_ms,
             "eager_ms_per_step": eager_ms,
             "rspmm_kernel_only": {"kernel": "quad_kernel<FWD,add,mul,unit_w> (entity graph, F = %d: tail and head queries of the batch in one launch)" % Fk,
                                   "launches_timed": len(kernel_ms), "avg_ms": k_avg_ms,
                                   "timed": "every launch of the timed region" if graphed is None else
-                                           "24 eager launches of the same kernel/shapes right after the timed region "
-                                           "(event records cannot be captured into the hipGraph with this HIP runtime)",
+                                           "%d eager launches of the same kernel/shapes right after the timed region "
+                                           "(event records cannot be captured into the hipGraph with this HIP runtime)" % len(kernel_ms),
                                   "edges_per_s": E * (Fk // 64) / (k_avg_ms * 1e-3) if kernel_ms else None},
-            "roofline": {"bound": "hbm", "achieved": algo / (k_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "algorithmic bytes/launch = %d (SURVEY 8d); input (%.0f MB) is Infinity-Cache/L2 "
-                                 "resident at this size, so achieved may exceed HBM peak" % (algo, n_node * Fk * 4 / 1e6)},
+            "roofline": {"bound": "l2-gather", "kernel": "quad_kernel<FWD,add,mul,unit_w,8>",
+                         "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
+                         "algorithmic_bytes": algo, "kernel_ms": k_avg_ms,
+                         "l2_gather_ceiling": list(L2_GATHER_CEILING_GBS),
+                         "frac_of_l2_gather_ceiling": achieved / L2_GATHER_CEILING_GBS[1],
+                         "hbm_compulsory_bytes": compulsory,
+                         "hbm_frac_on_compulsory_bytes": compulsory / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "note": "the gathered matrix (%.0f MB) is L2 / Infinity-Cache resident at this size: algorithmic "
+                                 "bytes (SURVEY 8d) are priced against the XCD-L2 peak (MI355X_MICROARCH.md: 34.5 TB/s; "
+                                 "measured ceiling for rows gathered from L2: 16.8-18.8 TB/s), HBM against the "
+                                 "compulsory bytes; the DRAM-bound regime is roofline_hbm" % (n_node * Fk * 4 / 1e6)},
             "mrr_hip": mrr,
             "mrr_hip_after_finetune": mrr_tuned,
             "mrr_check": mrr_check,
@@ -394,8 +501,10 @@ def main():
             und_np = {"dst": und.edge_list[:, 1].cpu().numpy(), "src": und.edge_list[:, 0].cpu().numpy(),
                       "rel": und.edge_list[:, 2].cpu().numpy()}
             result["cpu_baseline"] = cpu_baseline(und_np, n_node, R2, F)
-        if world == 1 and args.dram_probe:
-            result["roofline_dram_probe"] = dram_probe(dev, lib)
+        if world == 1 and args.stress:
+            del xk, rk
+            torch.cuda.empty_cache()
+            result["roofline_hbm"] = stress_roofline(dev, lib)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

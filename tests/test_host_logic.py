@@ -34,6 +34,21 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.UltraSegments) == 18 * 8          # struct layout of the header
 
 
+def test_torch_extension_registers_the_dispatcher_ops():
+    """libultra_torch_ext.so (csrc/torch_ext.cpp) loads without a GPU and registers torch.ops.ultra_mi.* with the
+    schemas SURVEY.md 8b names; CPU tensors are refused by the dispatcher itself (no CPU kernel is registered)."""
+    from ultra_torchdrug_amd import _lib, _torch_ext
+    ops = _torch_ext.load()
+    assert int(ops.abi_version()) == _lib.ABI_VERSION
+    schema = str(torch.ops.ultra_mi.rspmm_fwd.default._schema)
+    assert schema.startswith("ultra_mi::rspmm_fwd(Tensor row_ptr, Tensor src, Tensor rel, Tensor? w, Tensor relation, "
+                             "Tensor input, int sum_op, int mul_op) -> Tensor")
+    assert "Tensor[]" in str(torch.ops.ultra_mi.build_relcsr.default._schema)
+    i32 = lambda *v: torch.tensor(v, dtype=torch.int32)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        ops.rspmm_fwd(i32(0, 1), i32(0), i32(0), None, torch.randn(1, 4), torch.randn(1, 4), 0, 0)
+
+
 def test_operator_rejects_cpu_tensors_and_bad_names():
     from ultra_torchdrug_amd import RelCSR, generalized_rspmm
     e = torch.tensor([0, 1])

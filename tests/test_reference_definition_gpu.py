@@ -91,29 +91,33 @@ def test_operator_equals_reference_definition_at_baseline_shapes(name, weights, 
     want_d_rel, want_d_x = relation.grad.clone(), x.grad.clone()
 
     rows = has_edges.expand_as(out)
+    # bound of a length-n fp32 sum evaluated in two different orders: c * sqrt(n) * 2^-24 * (sum of |terms|), c = 32
+    # (the worst case is n * 2^-24 * S; the atomics of the ATen side add their own order).  Forward rows are short enough
+    # for the flat 1e-5 * S the reference tolerance asks for; a relation row of the gradient sums up to 80 000 terms.
+    def bound(n_terms, s_abs, floor):
+        return 32 * n_terms.clamp(min=1).float().sqrt().unsqueeze(-1) * 2.0 ** -24 * s_abs + floor
+    with torch.no_grad():
+        ones = torch.ones_like(x)
+        g_abs = grad.abs() * has_edges
+        rel_of = relation.abs() if mul == "mul" else torch.ones_like(relation)
+        x_of = x.abs() if mul == "mul" else ones
+        wa = torch.ones(len(dst), device=dev) if w is None else w.abs()
+        s_x = torch.zeros_like(x).index_add_(0, src, g_abs[dst] * rel_of[rel] * wa.unsqueeze(-1))
+        s_rel = torch.zeros_like(relation).index_add_(0, rel, g_abs[dst] * x_of[src] * wa.unsqueeze(-1))
+        n_x, n_rel_terms = torch.bincount(src, minlength=n), torch.bincount(rel, minlength=n_rel)
     if sum == "add":
         with torch.no_grad():
             scale = reference_rspmm(dst, src, rel, None if w is None else w.abs(), relation.abs(), x.abs(), n, "add", mul)
         assert ((out - want).abs() <= 1e-5 * scale + 1e-6)[rows].all()
         assert (out[~rows] == 0).all()
-        # gradients are sums of the same kind: bound them by the same reduction over absolute values
-        with torch.no_grad():
-            ones = torch.ones_like(x)
-            g_abs = grad.abs() * has_edges
-            rel_of = relation.abs() if mul == "mul" else torch.ones_like(relation)
-            x_of = x.abs() if mul == "mul" else ones
-            wa = torch.ones(len(dst), device=dev) if w is None else w.abs()
-            s_x = torch.zeros_like(x).index_add_(0, src, g_abs[dst] * rel_of[rel] * wa.unsqueeze(-1))
-            s_rel = torch.zeros_like(relation).index_add_(0, rel, g_abs[dst] * x_of[src] * wa.unsqueeze(-1))
-        assert ((d_x - want_d_x).abs() <= 1e-5 * s_x + 1e-6).all()
-        assert ((d_rel - want_d_rel).abs() <= 1e-5 * s_rel + 1e-5).all()
     else:
         assert torch.equal(out[rows], want[rows]), "min/max differ from the reference definition"
         fmax = torch.finfo(torch.float32).max
         assert (out[~rows] == (fmax if sum == "min" else -fmax)).all()
-        # the selected edge receives the gradient in both formulations (distinct random messages: no ties)
-        torch.testing.assert_close(d_x, want_d_x, rtol=1e-5, atol=1e-5)
-        torch.testing.assert_close(d_rel, want_d_rel, rtol=1e-4, atol=1e-3)
+    # gradients: sums over the edges of a source node / of a relation (for min / max over the selected edges only --
+    # distinct random messages, no ties -- which the sums over all edges bound from above)
+    assert ((d_x - want_d_x).abs() <= bound(n_x, s_x, 1e-6)).all()
+    assert ((d_rel - want_d_rel).abs() <= bound(n_rel_terms, s_rel, 1e-5)).all()
 
 
 def _entity_model(aggregate_func, message_func, n_rel_base, layers=3):
@@ -156,7 +160,10 @@ def test_entity_stack_hip_path_equals_aten_definition_path(name, layers):
 @pytest.mark.parametrize("message_func", ["distmult", "transe"])
 def test_every_aggregate_and_message_of_the_layers_matches_the_aten_definition(aggregate_func, message_func):
     """All aggregate functions (sum / mean / max / pna = mean, max, min, std) x both rspmm messages of
-    GeneralizedRelationalConvNBFMod on S-wn18rr (B = 2), forward AND parameter / input gradients."""
+    GeneralizedRelationalConvNBFMod on S-wn18rr (B = 2), forward AND parameter / input gradients.
+    Yardstick: the ATen definition path in FLOAT64 is the truth; the HIP path (fp32) must be as close to it as the
+    ATen definition path in fp32 is (hub nodes sum thousands of messages, LayerNorm and ReLU sit in between, so a
+    fixed tolerance would measure the conditioning of the network, not the kernels)."""
     if aggregate_func == "pna" and message_func == "transe":
         pytest.skip("the reference's own two branches disagree here: its rspmm branch squares the OPERANDS for the "
                     "std term (ultra/layer.py:367), not the message (:287-288); mirrored as is")
@@ -166,37 +173,40 @@ def test_every_aggregate_and_message_of_the_layers_matches_the_aten_definition(a
     triples, n, r = synthetic_triples("S-wn18rr", 1024)
     B = 2
     results = {}
-    for path in ("hip", "aten"):
+    for path in ("hip", "aten", "aten64"):
+        dtype = torch.float64 if path == "aten64" else torch.float32
         torch.manual_seed(7)
         model = _entity_model(aggregate_func, message_func, r, layers=2).to(dev).train()
         graph = model._undirected(Graph(torch.from_numpy(triples).to(dev), num_node=n, num_relation=r))
         gen = torch.Generator(device=dev).manual_seed(3)
-        rel_repr = torch.randn(B, 2 * r, 64, device=dev, generator=gen).requires_grad_()
+        rel_repr = torch.randn(B, 2 * r, 64, device=dev, generator=gen)
         h_index = torch.randint(0, n, (B,), device=dev, generator=gen)
         r_index = torch.randint(0, 2 * r, (B,), device=dev, generator=gen)
-        probe = torch.randn(n, B, 128, device=dev, generator=gen)
+        probe = torch.randn(n, B, 128, device=dev, generator=gen).to(dtype)
+        model.to(dtype)
+        rel_repr = rel_repr.to(dtype).requires_grad_()
         model.query = rel_repr
         for conv in model.layers:
             conv.relation = rel_repr
-        feature = model.bellmanford(graph, h_index, r_index, separate_grad=(path == "aten"))["node_feature"]
+        feature = model.bellmanford(graph, h_index, r_index, separate_grad=(path != "hip"))["node_feature"]
         (feature * probe).sum().backward()
-        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-        grads["relation_representations"] = rel_repr.grad.clone()
-        results[path] = (feature.detach(), grads)
-    f_hip, g_hip = results["hip"]
-    f_aten, g_aten = results["aten"]
-    scale = f_aten.abs().max().item()
+        grads = {k: p.grad.double() for k, p in model.named_parameters() if p.grad is not None}
+        grads["relation_representations"] = rel_repr.grad.double()
+        results[path] = (feature.detach().double(), grads)
+    f_true, g_true = results["aten64"]
+    scale = f_true.abs().max().item()
+    err = lambda a, b: (a - b).abs().max().item()
+    e_hip, e_aten = err(results["hip"][0], f_true), err(results["aten"][0], f_true)
+    assert e_hip <= 4 * e_aten + 1e-5 * scale, "features: HIP %.3g vs ATen-fp32 %.3g away from fp64" % (e_hip, e_aten)
     if aggregate_func == "pna":
-        # std = sqrt(clamp(E[m^2] - E[m]^2, eps = 1e-6)) (layer.py:288-289): the subtraction cancels, and the square root
-        # at the clamp amplifies a rounding difference by 1 / (2 sqrt(eps)) = 500 -- and its derivative jumps from 0 to
-        # 500 across the clamp, so the gradients of the two (equally valid) summation orders are not comparable
-        assert (f_hip - f_aten).abs().max().item() <= 2e-3 * scale
+        # std = sqrt(clamp(E[m^2] - E[m]^2, eps = 1e-6)) (layer.py:288-289): its derivative jumps from 0 to
+        # 1 / (2 sqrt(eps)) = 500 across the clamp, where fp32 and fp64 land on different sides: forward only
         return
-    assert (f_hip - f_aten).abs().max().item() <= 2e-4 * scale
-    assert g_hip.keys() == g_aten.keys() and "layers.0.linear.weight" in g_hip
-    for k in g_aten:
-        s = g_aten[k].abs().max().item() + 1e-8
-        assert (g_hip[k] - g_aten[k]).abs().max().item() <= 5e-4 * s + 1e-6, k
+    assert results["hip"][1].keys() == g_true.keys() and "layers.0.linear.weight" in g_true
+    for k in g_true:
+        s = g_true[k].abs().max().item() + 1e-12
+        e_hip, e_aten = err(results["hip"][1][k], g_true[k]), err(results["aten"][1][k], g_true[k])
+        assert e_hip <= 4 * e_aten + 1e-5 * s, "%s: HIP %.3g vs ATen-fp32 %.3g away from fp64 (scale %.3g)" % (k, e_hip, e_aten, s)
 
 
 def test_relation_stack_hip_path_equals_aten_definition_path():

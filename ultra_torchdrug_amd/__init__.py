@@ -17,5 +17,10 @@ def library_path():
 
 
 def require_library():
-    """Load ``libultra_rspmm.so`` now (raises if it is missing: there is no fallback path)."""
-    return _lib.load()
+    """Load ``libultra_rspmm.so`` -- and the PyTorch extension on top of it unless ``ULTRA_BINDING=ctypes`` -- now
+    (raises if one is missing: there is no fallback path)."""
+    lib = _lib.load()
+    from . import _torch_ext
+    if _torch_ext.binding() == "torch":
+        _torch_ext.load()
+    return lib

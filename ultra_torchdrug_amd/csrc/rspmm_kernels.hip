@@ -1441,6 +1441,14 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
     if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(relation) |
          reinterpret_cast<uintptr_t>(boundary_value)) & 15u) return ULTRA_ERR_BAD_SHAPE;      // 16-byte row segments
     hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t ev_start = g_prof_start, ev_stop = g_prof_stop;         // ultra_rspmm_profile_next: zero fill + kernel
+    g_prof_start = g_prof_stop = nullptr;
+    if (ev_start != nullptr || ev_stop != nullptr) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        HIP_TRY(hipStreamIsCapturing(s, &cs));
+        if (cs != hipStreamCaptureStatusNone) ev_start = ev_stop = nullptr;
+    }
+    if (ev_start != nullptr) HIP_TRY(hipEventRecord(ev_start, s));
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_dst * (size_t)F * sizeof(float), s));
     FrontierParams p;
     p.src_ptr = src_ptr;
@@ -1459,6 +1467,7 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
     if (by_src->weight == nullptr) hipLaunchKernelGGL(frontier_kernel<true>, grid, dim3(kFrontierThreads), 0, s, p);
     else hipLaunchKernelGGL(frontier_kernel<false>, grid, dim3(kFrontierThreads), 0, s, p);
     HIP_TRY(hipGetLastError());
+    if (ev_stop != nullptr) HIP_TRY(hipEventRecord(ev_stop, s));
     return ULTRA_OK;
 }
 

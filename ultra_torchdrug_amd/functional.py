@@ -14,7 +14,7 @@ import collections
 
 import torch
 
-from . import _lib
+from . import _lib, _torch_ext
 from .relcsr import RelCSR
 
 __all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "RelCSR"]
@@ -114,8 +114,12 @@ def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, bou
             raise RuntimeError("boundary must be (int32 (B,), fp32 (B, D)) with B * D == %d on %s" % (F, out.device))
     if out.numel() == 0:
         return out
-    lib = _lib.load()
     seg = csr.fwd
+    if _torch_ext.binding() == "torch":         # through the dispatcher: torch.ops.ultra_mi (csrc/torch_ext.cpp)
+        b_node_, b_value_ = (boundary[0], b_value) if boundary is not None else (None, None)
+        return _torch_ext.load().rspmm_plan_fwd(seg.plan_tensor, relation, input, add_rows, b_node_, b_value_,
+                                                csr.shape[1], sum_op, mul_op)
+    lib = _lib.load()
     ws, ws_bytes = _workspace(seg, F, input.device)
     if boundary is not None:
         with torch.cuda.device(input.device):
@@ -209,9 +213,14 @@ def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mu
     d_relation = torch.empty_like(relation) if need_relation else None
     if F == 0 or (not need_input and not need_relation):
         return d_input, d_relation
-    lib = _lib.load()
     by_src = csr.by_src if need_input else None
     by_rel = csr.by_rel if need_relation else None
+    if _torch_ext.binding() == "torch":
+        d_in, d_rel = _torch_ext.load().rspmm_plan_bwd(
+            by_src.plan_tensor if by_src is not None else None, by_rel.plan_tensor if by_rel is not None else None,
+            relation, input, output, output_grad, csr.shape[1], csr.shape[0], sum_op, mul_op)
+        return (d_in if need_input else None), (d_rel if need_relation else None)
+    lib = _lib.load()
     n_ws = max(by_src.n_pieces if by_src is not None else 0, by_rel.n_pieces if by_rel is not None else 0) * F
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
     with torch.cuda.device(dev):

@@ -104,7 +104,7 @@ class TransferNBFNet(nn.Module):
         else:
             query = self.query[torch.arange(bs, device=graph.device), r_index]
         index = h_index.unsqueeze(-1).expand_as(query)
-        boundary = torch.zeros(graph.num_node, *query.shape, device=query.device)
+        boundary = torch.zeros(graph.num_node, *query.shape, device=query.device, dtype=query.dtype)
         boundary.scatter_add_(0, index.unsqueeze(0), query.unsqueeze(0))
         graph.query = query
         graph.boundary = boundary

@@ -200,6 +200,15 @@ class Segments:
     def pointer(self):
         return ctypes.byref(self.struct)
 
+    @property
+    def plan_tensor(self):
+        """The ``ultra_segments`` struct as a CPU uint8 tensor (shares the struct's memory): the form in which a plan
+        crosses the PyTorch dispatcher to ``torch.ops.ultra_mi.rspmm_plan_*`` (csrc/torch_ext.cpp)."""
+        if getattr(self, "_plan_tensor", None) is None or self._plan_tensor_of is not self.struct:
+            self._plan_tensor = torch.frombuffer(self.struct, dtype=torch.uint8)
+            self._plan_tensor_of = self.struct
+        return self._plan_tensor
+
     def reweighted(self, weight):
         """Shallow copy that shares every index array / schedule of this plan and carries other edge weights
         (``weight``: fp32 [n_edges] in THIS plan's edge order)."""
