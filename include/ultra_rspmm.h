@@ -234,6 +234,21 @@ int ultra_combine_dxdu_f32(const float *d_z, const float *weight, const float *g
                            int64_t rows, int64_t dim, void *stream);
 
 
+/* The same backward in ONE pass over the rows (csrc/combine_fused_bwd.inc): a wave keeps a 32-row tile in LDS through the
+ * three GEMMs (recompute z, d_weight, d_input | d_update), so the rows are read once (input, update, grad_out) and written
+ * once (d_input, d_update) instead of the 8 reads + 3 writes of the two calls above; d_input / d_update carry the same
+ * bits as ultra_combine_dxdu_f32, the parameter gradients come out finished (partials added in wave order).
+ *   shortcut          : d_input += grad_out (the caller's `hidden + layer_input`, ultra/model.py:126-127)
+ *   d_weight [64,128], d_bias [64] or NULL, d_ln_weight / d_ln_bias [64] (ignored without LayerNorm)
+ *   partial_workspace : ultra_combine_backward_fused_waves() * (64 * 128 + 192) floats of scratch */
+int ultra_combine_backward_fused_waves(int device, int64_t rows, int *n_waves);
+int ultra_combine_backward_fused_f32(const float *input, const float *update, const float *weight, const float *bias,
+                                     const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                                     const float *grad_out, float *d_input, float *d_update, float *d_weight,
+                                     float *d_bias, float *d_ln_weight, float *d_ln_bias, float *partial_workspace,
+                                     size_t workspace_bytes, int64_t rows, int64_t dim, void *stream);
+
+
 /*
  * out[rows, out_dim] = relu?( input[rows, in_dim] . weight[out_dim, in_dim]^T + bias ) in a documented summation order
  * (k-ordered fmaf chain from the bias: k = 0, in_dim/2, 1, in_dim/2 + 1, ...; for out_dim == 1: k ascending), so that

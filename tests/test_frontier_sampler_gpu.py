@@ -319,3 +319,39 @@ def test_rowgroup_kernel_and_raw_csr_entry_match_oracle(oracle, case):
         d_rel_o, d_x_o = oracle.rspmm_backward(csr_o, relation, x, out, grad, "add", m, piece=csr.piece_len)
         d_x, d_rel = UF.rspmm_backward(csr, rel_t, x_t, None, g_t, "add", m)
         assert np.array_equal(d_x.cpu().numpy(), d_x_o) and np.array_equal(d_rel.cpu().numpy(), d_rel_o), m
+
+
+# ------------------------------------------------------------------------------------------------ fused epilogue backward
+@pytest.mark.parametrize("rows", [1, 31, 33, 1000, 65536 + 7, 232656])
+@pytest.mark.parametrize("ln,relu,shortcut", [(True, True, True), (False, True, False), (True, False, False)])
+def test_one_pass_combine_backward_equals_three_kernel_backward(monkeypatch, rows, ln, relu, shortcut):
+    """csrc/combine_fused_bwd.inc (one pass over the rows) against the three-kernel backward of combine_train.inc:
+    d_input / d_update carry the SAME bits (same k order of the fmaf chains); the parameter gradients are sums over
+    the rows taken in another order (tiles dealt round-robin to waves instead of contiguous row ranges): fp32
+    tolerance 2e-5 of each gradient's scale, the bar of the autograd test in tests/test_rspmm_gpu.py."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = _dev()
+    gen = torch.Generator(device=dev).manual_seed(rows)
+    x = torch.randn(rows, 64, device=dev, generator=gen)
+    u = torch.randn(rows, 64, device=dev, generator=gen) * 2
+    gout = torch.randn(rows, 64, device=dev, generator=gen)
+    torch.manual_seed(rows + 1)
+    lin, norm = torch.nn.Linear(128, 64).to(dev), torch.nn.LayerNorm(64).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(64, device=dev) + 0.5)
+        norm.bias.copy_(torch.randn(64, device=dev) * 0.1)
+    results = {}
+    for mode in ("fused", "split"):
+        monkeypatch.setenv("ULTRA_COMBINE_BWD", mode)
+        leaves = [t.detach().clone().requires_grad_() for t in (x, u, lin.weight, lin.bias, norm.weight, norm.bias)]
+        out = UF.combine(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4] if ln else None, leaves[5] if ln else None,
+                         norm.eps, relu, shortcut)
+        out.backward(gout)
+        results[mode] = [t.grad for t in (leaves if ln else leaves[:4])]
+    names = ["d_input", "d_update", "d_weight", "d_bias", "d_ln_weight", "d_ln_bias"]
+    for name, a, b in zip(names, results["fused"], results["split"]):
+        if name in ("d_input", "d_update"):
+            assert torch.equal(a, b), name
+        else:
+            scale = b.abs().max().item() + 1e-12
+            assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-6, name

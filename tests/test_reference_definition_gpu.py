@@ -202,6 +202,15 @@ def test_every_aggregate_and_message_of_the_layers_matches_the_aten_definition(a
         # std = sqrt(clamp(E[m^2] - E[m]^2, eps = 1e-6)) (layer.py:288-289): its derivative jumps from 0 to
         # 1 / (2 sqrt(eps)) = 500 across the clamp, where fp32 and fp64 land on different sides: forward only
         return
+    if aggregate_func == "max":
+        # Ties are systematic here, not accidental: every node the first layer did not reach carries the SAME hidden
+        # row, so two in-edges of one relation from such nodes send bit-identical messages.  Who receives the gradient
+        # of a tied maximum is a convention on which the reference's own branches differ: torchdrug's rspmm backward
+        # feeds EVERY edge whose message equals the output (mirrored by the HIP kernels and the oracle), torch_scatter's
+        # scatter_max in the materialised branch (layer.py:280) feeds ONE of them, and ATen's scatter_reduce("amax")
+        # used for that branch here splits it evenly.  The forward is compared; the gradient of `max` is pinned by the
+        # oracle tests on tie-free inputs (tests/test_rspmm_gpu.py::test_backward_matches_oracle).
+        return
     assert results["hip"][1].keys() == g_true.keys() and "layers.0.linear.weight" in g_true
     for k in g_true:
         s = g_true[k].abs().max().item() + 1e-12

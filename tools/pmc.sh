@@ -4,6 +4,8 @@
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
+PY=$(readlink -f "$(command -v python3)")     # the ELF interpreter itself: no shim may exec after the profiler's preload
+if ! head -c 4 "$PY" | grep -q ELF; then echo "python3 resolves to $PY, which is not an ELF binary" >&2; exit 1; fi
 i=0
 for set in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
@@ -13,6 +15,6 @@ for set in \
   "WRITE_SIZE" \
   "GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python "$@" > "$out/pass$i.log" 2>&1
+  rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- "$PY" "$@" > "$out/pass$i.log" 2>&1
 done
 ls "$out"

@@ -60,6 +60,8 @@ EXPORTS = (
     "ultra_combine_backward_waves",
     "ultra_combine_backward_f32",
     "ultra_combine_dxdu_f32",
+    "ultra_combine_backward_fused_waves",
+    "ultra_combine_backward_fused_f32",
     "ultra_linear_forward_f32",
     "ultra_score_forward_f32",
     "ultra_relation_project_f32",
@@ -139,6 +141,11 @@ def load():
     lib.ultra_combine_backward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, vp, vp, vp, vp, vp, vp, i64, i64, vp]
     lib.ultra_combine_dxdu_f32.restype = i32
     lib.ultra_combine_dxdu_f32.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp]
+    lib.ultra_combine_backward_fused_waves.restype = i32
+    lib.ultra_combine_backward_fused_waves.argtypes = [i32, i64, ctypes.POINTER(i32)]
+    lib.ultra_combine_backward_fused_f32.restype = i32
+    lib.ultra_combine_backward_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp, vp, vp, vp,
+                                                     vp, vp, sz, i64, i64, vp]
     lib.ultra_linear_forward_f32.restype = i32
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.ultra_score_forward_f32.restype = i32

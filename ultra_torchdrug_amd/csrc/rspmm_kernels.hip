@@ -1462,7 +1462,9 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
     p.out = out;
     p.F = F;
     p.piece_len = (int)by_src->piece_len;
-    p.slices = 4;
+    // 64 workgroups x 16 groups per query: a hub head with tens of thousands of out-edges still leaves every group a
+    // few dozen (the groups of a low-degree query find an empty slice and exit)
+    p.slices = 64;
     const dim3 grid((unsigned)(F / 64), (unsigned)p.slices);
     if (by_src->weight == nullptr) hipLaunchKernelGGL(frontier_kernel<true>, grid, dim3(kFrontierThreads), 0, s, p);
     else hipLaunchKernelGGL(frontier_kernel<false>, grid, dim3(kFrontierThreads), 0, s, p);
@@ -1587,5 +1589,6 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
 }  // extern "C"
 
 #include "combine_train.inc"
+#include "combine_fused_bwd.inc"
 #include "dense.inc"
 #include "sampler.inc"

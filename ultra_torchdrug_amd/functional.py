@@ -452,6 +452,30 @@ class _CombineFunction(torch.autograd.Function):
         lib = _lib.load()
         dev = input.device
         import ctypes
+        import os
+        if os.environ.get("ULTRA_COMBINE_BWD", "fused") == "fused":
+            # one pass over the rows: recompute z, LayerNorm / ReLU backward, d_weight, d_input | d_update (3 row-sized
+            # reads + 2 writes); parameter gradients come out finished.  ULTRA_COMBINE_BWD=split: the three-kernel form.
+            has_ln = ln_weight is not None
+            n_waves = ctypes.c_int(0)
+            _lib.check(lib.ultra_combine_backward_fused_waves(dev.index or 0, rows, ctypes.byref(n_waves)))
+            ws = torch.empty(n_waves.value * (64 * 128 + 192), dtype=torch.float32, device=dev)
+            d_input, d_update = torch.empty_like(input_c), torch.empty_like(update_c)
+            d_weight = torch.empty(64, 128, dtype=torch.float32, device=dev)
+            d_bias = torch.empty(64, dtype=torch.float32, device=dev)
+            d_g = torch.empty(64, dtype=torch.float32, device=dev) if has_ln else None
+            d_b = torch.empty(64, dtype=torch.float32, device=dev) if has_ln else None
+            with torch.cuda.device(dev):
+                _lib.check(lib.ultra_combine_backward_fused_f32(
+                    input_c.data_ptr(), update_c.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                    ln_weight.contiguous().data_ptr() if has_ln else None, ln_bias.contiguous().data_ptr() if has_ln else None,
+                    ln_eps, int(relu), int(shortcut), grad_out.data_ptr(), d_input.data_ptr(), d_update.data_ptr(),
+                    d_weight.data_ptr(), d_bias.data_ptr(), d_g.data_ptr() if has_ln else None,
+                    d_b.data_ptr() if has_ln else None, ws.data_ptr(), ws.numel() * 4, rows, 64, _stream()))
+            needs = ctx.needs_input_grad
+            return (d_input.view_as(input) if needs[0] else None, d_update.view_as(update) if needs[1] else None,
+                    d_weight if needs[2] else None, d_bias if needs[3] else None, d_g if (has_ln and needs[4]) else None,
+                    d_b if (has_ln and needs[5]) else None, None, None, None)
         n_ln, n_wg = ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(lib.ultra_combine_backward_waves(dev.index or 0, rows, ctypes.byref(n_ln), ctypes.byref(n_wg)))
         d_z = torch.empty(rows, 64, dtype=torch.float32, device=dev)

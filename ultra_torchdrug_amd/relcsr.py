@@ -351,12 +351,14 @@ class RelCSR:
         self._opts.update(chunk_edges=self.chunk_edges, piece_len=self.piece_len)
         self._fwd = self._by_src = self._by_rel = None
 
-    def _coalesce_native(self, dst, src, rel, weight):
-        """``ultra_relcsr_coalesce`` (csrc/relcsr_build.hip): radix sort of the 64-bit triple key + duplicate merge."""
+    def _coalesce_native(self, dst, src, rel, weight, dims=None):
+        """``ultra_relcsr_coalesce`` (csrc/relcsr_build.hip): radix sort of the 64-bit triple key + duplicate merge.
+        ``dims``: ranges of the three key columns (default: this adjacency's ``(n_dst, n_src, n_rel)``)."""
         lib = _lib.load()
         dev, n = dst.device, int(dst.shape[0])
-        n_dst, n_src, n_rel = self.shape
-        dst, src, rel, weight = dst.contiguous(), src.contiguous(), rel.contiguous(), weight.contiguous()
+        n_dst, n_src, n_rel = self.shape if dims is None else dims
+        dst, src, rel = dst.contiguous(), src.contiguous(), rel.contiguous()
+        weight = weight.contiguous() if weight is not None else None
         out_idx = torch.empty(3, n, dtype=torch.int32, device=dev)
         out_w = torch.empty(n, dtype=torch.float32, device=dev)
         edge_of_input = torch.empty(n, dtype=torch.long, device=dev)
@@ -364,7 +366,8 @@ class RelCSR:
         n_unique, unit = ctypes.c_int64(0), ctypes.c_int(1)
         with torch.cuda.device(dev):
             _lib.check(lib.ultra_relcsr_coalesce(
-                dst.data_ptr(), src.data_ptr(), rel.data_ptr(), weight.data_ptr(), n, n_dst, n_src, n_rel,
+                dst.data_ptr(), src.data_ptr(), rel.data_ptr(), weight.data_ptr() if weight is not None else None, n, n_dst,
+                n_src, n_rel,
                 out_idx[0].data_ptr(), out_idx[1].data_ptr(), out_idx[2].data_ptr(), out_w.data_ptr(),
                 edge_of_input.data_ptr(), ctypes.byref(n_unique), ctypes.byref(unit), temp.data_ptr(), temp.numel(),
                 torch.cuda.current_stream().cuda_stream))
@@ -408,6 +411,20 @@ class RelCSR:
                                  n_rel_table=self.shape[2], **self._opts)
         return self._fwd
 
+    def _reorder(self, first, second, third, dims):
+        """The coalesced edges sorted by ``(first, second, third)``: returns the three sorted columns and ``order``
+        (sorted position -> index in forward order).  On the device this is the library's radix sort over the
+        significant key bits (the edges are already distinct, so nothing merges); torch.sort otherwise."""
+        if self._opts.get("builder") != "torch" and first.is_cuda and first.numel() and \
+                (self._opts.get("builder") or os.environ.get("ULTRA_RELCSR_BUILDER") or "native") == "native":
+            a, b, c, _w, position, _unit = self._coalesce_native(first, second, third, None, dims)
+            order = torch.empty_like(position)
+            order[position] = torch.arange(position.numel(), device=position.device)
+            return a, b, c, order
+        key = (first * dims[1] + second) * max(dims[2], 1) + third
+        order = torch.sort(key, stable=True).indices
+        return first[order], second[order], third[order], order
+
     @property
     def by_src(self):
         if self._by_src is None and getattr(self, "_base", None) is not None:
@@ -415,10 +432,9 @@ class RelCSR:
             self._by_src = base.reweighted(self.weight[self._base._by_src_order])
         if self._by_src is None:
             n_dst, n_src, n_rel = self.shape
-            key = (self.src * n_dst + self.dst) * max(n_rel, 1) + self.rel_id
-            order = torch.sort(key, stable=True).indices
+            src, dst, rel, order = self._reorder(self.src, self.dst, self.rel_id, (n_src, n_dst, n_rel))
             self._by_src_order = order
-            self._by_src = Segments(self.src[order], self.dst[order], None, self.rel_id[order], self._w(order), n_src,
+            self._by_src = Segments(src, dst, None, rel, self._w(order), n_src,
                                     lds_rel_rows=n_rel, n_gather_rows=n_dst, n_node_a=n_dst, n_rel_table=n_rel,
                                     **self._opts)
         return self._by_src
@@ -430,11 +446,10 @@ class RelCSR:
             self._by_rel = base.reweighted(self.weight[self._base._by_rel_order])
         if self._by_rel is None:
             n_dst, n_src, n_rel = self.shape
-            key = (self.rel_id * n_dst + self.dst) * n_src + self.src
-            order = torch.sort(key, stable=True).indices
+            rel, dst, src, order = self._reorder(self.rel_id, self.dst, self.src, (n_rel, n_dst, n_src))
             self._by_rel_order = order
-            self._by_rel = Segments(self.rel_id[order], self.src[order], self.dst[order], self.rel_id[order],
-                                    self._w(order), n_rel, n_node_a=n_src, n_rel_table=n_rel, **self._opts)
+            self._by_rel = Segments(rel, src, dst, rel, self._w(order), n_rel, n_node_a=n_src, n_rel_table=n_rel,
+                                    **self._opts)
         return self._by_rel
 
     @property
