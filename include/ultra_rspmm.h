@@ -182,6 +182,16 @@ int ultra_rspmm_backward_f32(const ultra_segments *by_src_host, const ultra_segm
                              size_t workspace_bytes, int64_t n_src, int64_t n_dst, int64_t n_rel, int64_t F,
                              int sum_op, int mul_op, void *stream);
 
+/* The same with d_input = d_input_add + (gradient through the edges): the rows of `input` usually receive a second
+ * gradient from the layer's dense epilogue (cat[input, update] -> Linear, plus the shortcut), which autograd would add in a
+ * pass of its own; here it rides in the kernel's row epilogue.  sum = add only; d_input_add [n_src, F] may be the same
+ * buffer as d_input (every element is read before it is written); NULL: exactly ultra_rspmm_backward_f32. */
+int ultra_rspmm_backward_accumulate_f32(const ultra_segments *by_src_host, const ultra_segments *by_rel_host,
+                                        const float *relation, const float *input, const float *output,
+                                        const float *output_grad, const float *d_input_add, float *d_input,
+                                        float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_src,
+                                        int64_t n_dst, int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream);
+
 /*
  * d_weight[e] = sum_f output_grad[dst_e, f] * [out == y] * (relation[r_e, f] MUL input[src_e, f])
  * (the value gradient torchdrug returns when sparse.requires_grad), edges in forward-plan order.

@@ -109,6 +109,16 @@ class OracleFunctional:
         out = self.generalized_rspmm(sparse, relation, input, sum="add", mul=mul)
         return out + (add_rows if boundary is None else self._dense_boundary(boundary, out.shape[0]))
 
+    def sum_layer(self, csr, relation, input, boundary_dense, boundary_sparse, mul, weight, bias, ln_weight=None,
+                  ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False):
+        """The layer the reference's way, op by op (layer.py:298-392, model.py:126-127)."""
+        shape = input.shape
+        if boundary_sparse is not None:
+            update = self.rspmm_sum_plus(csr, relation, input.flatten(1), None, mul=mul, boundary=boundary_sparse)
+        else:
+            update = self.rspmm_sum_plus(csr, relation, input.flatten(1), boundary_dense.flatten(1), mul=mul)
+        return self.combine(input, update.view(shape), weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
+
     @staticmethod
     def frontier_supported(sum, mul, F):
         return sum == "add" and mul == "mul" and F % 64 == 0

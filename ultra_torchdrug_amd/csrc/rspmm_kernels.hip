@@ -43,6 +43,10 @@ constexpr int kUnroll = ULTRA_UNROLL;   // gathers in flight per wave
 #ifndef ULTRA_UNROLL_BIG
 #define ULTRA_UNROLL_BIG 8
 #endif
+// cache policy of the big-graph gathers (aux of raw_buffer_load: 0 default, 2 nt): every row is touched ~10 times but far apart
+#ifndef ULTRA_BIG_GATHER_AUX
+#define ULTRA_BIG_GATHER_AUX 0
+#endif
 constexpr int kUnrollBig = ULTRA_UNROLL_BIG;   // ... for the big-graph variants of packed_kernel (DRAM gathers; 16 measured 3 % slower); <= PACK_SLACK
 constexpr int kXcd = 8;
 constexpr int kFixUnroll = 16;
@@ -143,9 +147,11 @@ struct ChunkWalker {
     }
     __device__ __forceinline__ void store_row(int r, float v) const {
         if (active) {
-            if constexpr (KIND == KIND_FWD) {
+            // add_rows: forward -- the fused boundary epilogue; d_input -- the gradient the same rows receive from the
+            // layer's epilogue (ultra_rspmm_backward_accumulate_f32; may alias `out`: read before it is written)
+            if constexpr (KIND != KIND_DREL) {
                 if (p.add_rows != nullptr) v = reduce<RED>(v, p.add_rows[(long long)r * F + col]);
-                else if (p.bnode != nullptr) v = reduce<RED>(v, (r == p.bnode[col / p.bdim]) ? p.bvec[col] : 0.0f);
+                else if (KIND == KIND_FWD && p.bnode != nullptr) v = reduce<RED>(v, (r == p.bnode[col / p.bdim]) ? p.bvec[col] : 0.0f);
             }
             p.out[(long long)r * F + col] = v;
         }
@@ -422,9 +428,9 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
         }
         auto store_row = [&](int r, float v) {
             if (active) {
-                if constexpr (KIND == KIND_FWD) {
+                if constexpr (KIND != KIND_DREL) {
                     if (p.add_rows != nullptr) v = reduce<RED>(v, p.add_rows[(long long)r * F + col]);
-                    else if (p.bnode != nullptr) v = reduce<RED>(v, (r == b_node) ? b_val : 0.0f);
+                    else if (KIND == KIND_FWD && p.bnode != nullptr) v = reduce<RED>(v, (r == b_node) ? b_val : 0.0f);
                 }
                 __builtin_nontemporal_store(v, &p.out[(long long)r * F + col]);   // streaming: keep the gathered rows in L2
             }
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     if constexpr (TWO_GATHERS) {
                         gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
                     } else if constexpr (BIG) {
-                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, m2[u] * p.row_bytes, 0));
+                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, m2[u] * p.row_bytes, ULTRA_BIG_GATHER_AUX));
                     } else {
                         gv[u] = gather_one(m[u]);
                     }
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
                     if constexpr (TWO_GATHERS) {
                         gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, voff, m2[u] * p.row_bytes, 0));
                     } else if constexpr (BIG) {
-                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, m2[u] * p.row_bytes, 0));
+                        gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, m2[u] * p.row_bytes, ULTRA_BIG_GATHER_AUX));
                     } else {
                         gv[u] = gather_one(m[u]);
                     }
@@ -1477,7 +1483,18 @@ int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments 
                              const float *input, const float *output, const float *output_grad, float *d_input,
                              float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_dst,
                              int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream) {
+    return ultra_rspmm_backward_accumulate_f32(by_src, by_rel, relation, input, output, output_grad, nullptr, d_input,
+                                               d_relation, workspace, workspace_bytes, n_src, n_dst, n_rel, F, sum_op,
+                                               mul_op, stream);
+}
+
+int ultra_rspmm_backward_accumulate_f32(const ultra_segments *by_src, const ultra_segments *by_rel, const float *relation,
+                                        const float *input, const float *output, const float *output_grad,
+                                        const float *d_input_add, float *d_input, float *d_relation, void *workspace,
+                                        size_t workspace_bytes, int64_t n_src, int64_t n_dst, int64_t n_rel, int64_t F,
+                                        int sum_op, int mul_op, void *stream) {
     if (output_grad == nullptr || relation == nullptr || input == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (d_input_add != nullptr && sum_op != ULTRA_SUM_ADD) return ULTRA_ERR_BAD_OP;       // the sum-aggregation kernels carry the epilogue
     if (sum_op != ULTRA_SUM_ADD && output == nullptr) return ULTRA_ERR_NULL_POINTER;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d_input != nullptr) {
@@ -1488,6 +1505,7 @@ int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments 
         p.output = output;
         p.grad = output_grad;
         p.out = d_input;
+        p.add_rows = d_input_add;
         const bool needs_rel = (mul_op == ULTRA_MUL_MUL) || (sum_op != ULTRA_SUM_ADD);
         int rc = run_plan<KIND_DX>(by_src, p, n_dst, 0, n_rel, F, sum_op, mul_op, needs_rel, workspace, workspace_bytes, s);
         if (rc) return rc;

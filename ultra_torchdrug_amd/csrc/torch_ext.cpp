@@ -18,7 +18,7 @@
 //   plan-based forms used by ultra_torchdrug_amd.functional (the plan = the bytes of one `ultra_segments` struct in a
 //   CPU uint8 tensor; the device arrays it points to are owned by the Python RelCSR object):
 //   ultra_mi::rspmm_plan_fwd(plan, relation, input, add_rows?, boundary_node?, boundary_value?, n_src, sum_op, mul_op) -> Tensor
-//   ultra_mi::rspmm_plan_bwd(by_src?, by_rel?, relation, input, output?, output_grad, n_src, n_dst, sum_op, mul_op)
+//   ultra_mi::rspmm_plan_bwd(by_src?, by_rel?, relation, input, output?, output_grad, d_input_add?, n_src, n_dst, sum_op, mul_op)
 //       -> (d_input, d_relation)
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -321,8 +321,8 @@ Tensor rspmm_plan_fwd(const Tensor &plan, const Tensor &relation, const Tensor &
 
 std::tuple<Tensor, Tensor> rspmm_plan_bwd(const optional<Tensor> &by_src, const optional<Tensor> &by_rel,
                                           const Tensor &relation, const Tensor &input, const optional<Tensor> &output,
-                                          const Tensor &output_grad, int64_t n_src, int64_t n_dst, int64_t sum_op,
-                                          int64_t mul_op) {
+                                          const Tensor &output_grad, const optional<Tensor> &d_input_add, int64_t n_src,
+                                          int64_t n_dst, int64_t sum_op, int64_t mul_op) {
     const ultra_segments *s_src = plan_of(by_src, "by_src"), *s_rel = plan_of(by_rel, "by_rel");
     check_dense(input, "input", at::kFloat, input);
     check_dense(relation, "relation", at::kFloat, input);
@@ -331,18 +331,32 @@ std::tuple<Tensor, Tensor> rspmm_plan_bwd(const optional<Tensor> &by_src, const 
     const int64_t F = input.size(1), n_rel = relation.size(0);
     Tensor rl = relation.contiguous(), x = input.contiguous(), g = output_grad.contiguous(), o;
     if (output.has_value() && output->defined()) o = output->contiguous();
-    Tensor d_input = s_src ? at::empty_like(x) : Tensor(), d_relation = s_rel ? at::empty_like(rl) : Tensor();
+    // d_input_add: the gradient the same rows receive from the layer's dense epilogue; accumulated IN PLACE (the kernels
+    // read every element before they write it), so no separate add pass and no extra (N, F) tensor
+    Tensor d_input, d_relation = s_rel ? at::empty_like(rl) : Tensor();
+    const float *add_ptr = nullptr;
+    if (s_src) {
+        if (d_input_add.has_value() && d_input_add->defined()) {
+            check_dense(*d_input_add, "d_input_add", at::kFloat, input);
+            TORCH_CHECK(d_input_add->sizes() == x.sizes() && d_input_add->is_contiguous(),
+                        "ultra_mi::rspmm_plan_bwd: d_input_add must be a contiguous tensor of the shape of input");
+            d_input = *d_input_add;
+            add_ptr = d_input.data_ptr<float>();
+        } else {
+            d_input = at::empty_like(x);
+        }
+    }
     if (F == 0 || (!s_src && !s_rel)) return {d_input, d_relation};
     const size_t ws_bytes = std::max(s_src ? ultra_rspmm_workspace_bytes(s_src, F) : 0,
                                      s_rel ? ultra_rspmm_workspace_bytes(s_rel, F) : 0);
     Tensor ws = at::empty({(int64_t)std::max<size_t>(ws_bytes / 4, 1)}, input.options());
-    check_status(ultra_rspmm_backward_f32(s_src, s_rel, rl.data_ptr<float>(), x.data_ptr<float>(),
-                                          o.defined() ? o.data_ptr<float>() : nullptr, g.data_ptr<float>(),
-                                          d_input.defined() ? d_input.data_ptr<float>() : nullptr,
-                                          d_relation.defined() ? d_relation.data_ptr<float>() : nullptr,
-                                          ws.data_ptr<float>(), ws_bytes, n_src, n_dst, n_rel, F, (int)sum_op, (int)mul_op,
-                                          current_stream(input)),
-                 "ultra_rspmm_backward_f32");
+    check_status(ultra_rspmm_backward_accumulate_f32(s_src, s_rel, rl.data_ptr<float>(), x.data_ptr<float>(),
+                                                     o.defined() ? o.data_ptr<float>() : nullptr, g.data_ptr<float>(), add_ptr,
+                                                     d_input.defined() ? d_input.data_ptr<float>() : nullptr,
+                                                     d_relation.defined() ? d_relation.data_ptr<float>() : nullptr,
+                                                     ws.data_ptr<float>(), ws_bytes, n_src, n_dst, n_rel, F, (int)sum_op,
+                                                     (int)mul_op, current_stream(input)),
+                 "ultra_rspmm_backward_accumulate_f32");
     return {d_input.defined() ? d_input : at::empty({0}, input.options()),
             d_relation.defined() ? d_relation : at::empty({0}, input.options())};
 }
@@ -357,7 +371,7 @@ TORCH_LIBRARY(ultra_mi, m) {
     m.def("rspmm_plan_fwd(Tensor plan, Tensor relation, Tensor input, Tensor? add_rows, Tensor? boundary_node, "
           "Tensor? boundary_value, int n_src, int sum_op, int mul_op) -> Tensor");
     m.def("rspmm_plan_bwd(Tensor? by_src, Tensor? by_rel, Tensor relation, Tensor input, Tensor? output, Tensor output_grad, "
-          "int n_src, int n_dst, int sum_op, int mul_op) -> (Tensor, Tensor)");
+          "Tensor(a!)? d_input_add, int n_src, int n_dst, int sum_op, int mul_op) -> (Tensor, Tensor)");
     m.def("abi_version() -> int", []() -> int64_t { return ultra_rspmm_abi_version(); });
 }
 

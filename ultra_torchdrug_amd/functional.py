@@ -204,12 +204,18 @@ def rspmm_frontier(csr, relation, boundary):
 
 
 def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mul", need_input=True,
-                   need_relation=True):
+                   need_relation=True, d_input_add=None):
+    """``(d_input, d_relation)``.  ``d_input_add`` (sum aggregation only): a contiguous ``(N_src, F)`` gradient the
+    same rows already hold (from the layer's dense epilogue); the edge gradient is accumulated INTO it inside the
+    kernel's row epilogue and the same tensor is returned -- no separate add pass."""
     sum_op, mul_op = _ops(sum, mul)
     relation, input, output_grad = relation.contiguous(), input.contiguous(), output_grad.contiguous()
     F = input.shape[1]
     dev = input.device
-    d_input = torch.empty_like(input) if need_input else None
+    if d_input_add is not None and (not need_input or sum != "add" or not d_input_add.is_contiguous()
+                                    or d_input_add.shape != input.shape or d_input_add.dtype != torch.float32):
+        raise RuntimeError("d_input_add: contiguous fp32 tensor of input's shape, sum aggregation, with need_input")
+    d_input = (d_input_add if d_input_add is not None else torch.empty_like(input)) if need_input else None
     d_relation = torch.empty_like(relation) if need_relation else None
     if F == 0 or (not need_input and not need_relation):
         return d_input, d_relation
@@ -218,16 +224,17 @@ def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mu
     if _torch_ext.binding() == "torch":
         d_in, d_rel = _torch_ext.load().rspmm_plan_bwd(
             by_src.plan_tensor if by_src is not None else None, by_rel.plan_tensor if by_rel is not None else None,
-            relation, input, output, output_grad, csr.shape[1], csr.shape[0], sum_op, mul_op)
+            relation, input, output, output_grad, d_input_add, csr.shape[1], csr.shape[0], sum_op, mul_op)
         return (d_in if need_input else None), (d_rel if need_relation else None)
     lib = _lib.load()
     n_ws = max(by_src.n_pieces if by_src is not None else 0, by_rel.n_pieces if by_rel is not None else 0) * F
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
     with torch.cuda.device(dev):
-        _lib.check(lib.ultra_rspmm_backward_f32(
+        _lib.check(lib.ultra_rspmm_backward_accumulate_f32(
             by_src.pointer if by_src is not None else None, by_rel.pointer if by_rel is not None else None,
             relation.data_ptr(), input.data_ptr(), output.data_ptr() if output is not None else None,
-            output_grad.data_ptr(), d_input.data_ptr() if d_input is not None else None,
+            output_grad.data_ptr(), d_input_add.data_ptr() if d_input_add is not None else None,
+            d_input.data_ptr() if d_input is not None else None,
             d_relation.data_ptr() if d_relation is not None else None, ws.data_ptr() if ws is not None else None,
             n_ws * 4, csr.shape[1], csr.shape[0], csr.shape[2], F, sum_op, mul_op, _stream()))
     return d_input, d_relation
@@ -568,6 +575,84 @@ class _RSPMMFunction(torch.autograd.Function):
             blocks = output_grad.view(output_grad.shape[0], n_query, -1)
             d_value = blocks[ctx.b_node.long(), torch.arange(n_query, device=output_grad.device)]
         return d_sparse, d_relation, d_input, None, None, None, d_add, None, d_value
+
+
+class _SumLayerFunction(torch.autograd.Function):
+    """One Bellman-Ford layer with summed messages as ONE autograd node:
+    ``out = combine(input, rspmm(adjacency, relation, input, sum="add") + boundary)``
+    (``ultra/layer.py:298-392`` + the caller's shortcut, ``ultra/model.py:126-127``).  Forward: the rspmm kernel with the
+    boundary epilogue, then the fused epilogue kernel.  Backward: the one-pass epilogue backward, then the rspmm
+    backward, which adds its edge gradient INTO the epilogue's ``d_input`` inside its row epilogue -- as separate
+    autograd nodes the two gradients of ``input`` meet in an extra add pass over an ``(N, B, 64)`` tensor per layer."""
+
+    @staticmethod
+    def forward(ctx, csr, relation, input, add_rows, b_node, b_value, mul, weight, bias, ln_weight, ln_bias, ln_eps,
+                relu, shortcut):
+        shape = input.shape                                      # (N, B, 64)
+        flat = input.flatten(1)
+        boundary = None if b_node is None else (b_node, b_value.detach())
+        update = rspmm_forward(csr, relation, flat, "add", mul, add_rows=None if add_rows is None else add_rows.flatten(1),
+                               boundary=boundary)
+        update = update.view(shape)
+        out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
+        ctx.csr, ctx.mul, ctx.b_node, ctx.has_add = csr, mul, b_node, add_rows is not None
+        ctx.flags = (float(ln_eps), bool(relu), bool(shortcut))
+        ctx.save_for_backward(relation, input, update, weight, bias, ln_weight, ln_bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import ctypes
+        relation, input, update, weight, bias, ln_weight, ln_bias = ctx.saved_tensors
+        ln_eps, relu, shortcut = ctx.flags
+        needs = ctx.needs_input_grad
+        shape = input.shape
+        dev = input.device
+        grad_out = grad_out.contiguous()
+        input_c, update_c = input.contiguous(), update.contiguous()
+        rows = input.numel() // 64
+        has_ln = ln_weight is not None
+        lib = _lib.load()
+        n_waves = ctypes.c_int(0)
+        _lib.check(lib.ultra_combine_backward_fused_waves(dev.index or 0, rows, ctypes.byref(n_waves)))
+        ws = torch.empty(n_waves.value * (64 * 128 + 192), dtype=torch.float32, device=dev)
+        d_input, d_update = torch.empty_like(input_c), torch.empty_like(update_c)
+        d_weight = torch.empty(64, 128, dtype=torch.float32, device=dev)
+        d_bias = torch.empty(64, dtype=torch.float32, device=dev)
+        d_g = torch.empty(64, dtype=torch.float32, device=dev) if has_ln else None
+        d_b = torch.empty(64, dtype=torch.float32, device=dev) if has_ln else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_combine_backward_fused_f32(
+                input_c.data_ptr(), update_c.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                ln_weight.contiguous().data_ptr() if has_ln else None, ln_bias.contiguous().data_ptr() if has_ln else None,
+                ln_eps, int(relu), int(shortcut), grad_out.data_ptr(), d_input.data_ptr(), d_update.data_ptr(),
+                d_weight.data_ptr(), d_bias.data_ptr(), d_g.data_ptr() if has_ln else None,
+                d_b.data_ptr() if has_ln else None, ws.data_ptr(), ws.numel() * 4, rows, 64, _stream()))
+        # the edge gradient accumulates into the epilogue's d_input (same buffer) inside the rspmm backward
+        flat_du = d_update.flatten(1)
+        d_in, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,
+                                          need_input=needs[2], need_relation=needs[1],
+                                          d_input_add=d_input.flatten(1) if needs[2] else None)
+        d_add = d_update if (ctx.has_add and needs[3]) else None
+        d_value = None
+        if ctx.b_node is not None and needs[5]:
+            n_query = ctx.b_node.shape[0]
+            d_value = d_update.view(shape[0], n_query, -1)[ctx.b_node.long(), torch.arange(n_query, device=dev)]
+        return (None, d_relation, d_in.view(shape) if d_in is not None else None, d_add, None, d_value, None,
+                d_weight if needs[7] else None, d_bias if needs[8] else None, d_g if (has_ln and needs[9]) else None,
+                d_b if (has_ln and needs[10]) else None, None, None, None)
+
+
+def sum_layer(csr, relation, input, boundary_dense, boundary_sparse, mul, weight, bias, ln_weight=None, ln_bias=None,
+              ln_eps=1e-5, relu=True, shortcut=False):
+    """A whole sum-aggregation layer for TRAINING as one autograd node (see :class:`_SumLayerFunction`):
+    ``[input +] relu(LN(Linear(cat[input, rspmm(csr, relation, input) + boundary])))``.  ``input``: ``(N, B, 64)``;
+    ``relation``: ``(R, B * 64)``; the boundary either dense ``(N, B, 64)`` or sparse ``(node int32 (B,), value (B, 64))``."""
+    _check_dense(csr, relation, input.flatten(1))
+    b_node, b_value = (None, None) if boundary_sparse is None else boundary_sparse
+    add_rows = boundary_dense if boundary_sparse is None else None
+    return _SumLayerFunction.apply(csr, relation, input, add_rows, b_node, b_value, mul, weight, bias, ln_weight, ln_bias,
+                                   ln_eps, relu, shortcut)
 
 
 def rspmm_sum_plus(sparse, relation, input, add_rows, mul="mul", boundary=None):

@@ -234,6 +234,16 @@ class TransferNBFNet(nn.Module):
             score = backend.get().score_all_entities(parts["hidden"], parts["query"], first.weight, first.bias,
                                                      second.weight, second.bias)
             return score.view(shape)
+        if not self.concat_hidden and not self.symmetric:
+            # candidates first, concatenation second: the (N, B, 128) node_feature of model.py:134-138 (and, in training,
+            # its equally large gradient) is never materialised -- cat([hidden, query])[t] == cat([hidden[t], query])
+            parts = self.bellmanford(graph, h_index[:, 0], r_index[:, 0], want_feature=False)
+            hidden, query = parts["hidden"], parts["query"]                # (N, B, 64), (B, 64)
+            if metric is not None:
+                self._feature_statistics(metric, hidden.detach(), query.detach())
+            rows = torch.arange(hidden.shape[1], device=hidden.device).unsqueeze(-1)
+            feature = torch.cat([hidden[t_index, rows], query.unsqueeze(1).expand(-1, t_index.shape[1], -1)], dim=-1)
+            return self.mlp(feature).squeeze(-1).view(shape)
         output = self.bellmanford(graph, h_index[:, 0], r_index[:, 0])
         feature = output["node_feature"].transpose(0, 1)
         if metric is not None:
@@ -251,6 +261,22 @@ class TransferNBFNet(nn.Module):
 
         score = self.mlp(feature).squeeze(-1)
         return score.view(shape)
+
+    @staticmethod
+    def _feature_statistics(metric, hidden, query):
+        """``output_norm / output_mean / output_std`` of model.py:178-180 for ``feature = cat[hidden, query]`` (query
+        repeated for every node) from ONE pass over ``hidden``: sums and sums of squares of the two parts add up."""
+        n_node = hidden.shape[0]
+        var_h, mean_h = torch.var_mean(hidden.float())
+        n_h = hidden.numel()
+        sum_h, sq_h = mean_h * n_h, var_h * (n_h - 1) + mean_h * mean_h * n_h
+        sum_q, sq_q = query.sum() * n_node, (query * query).sum() * n_node
+        n = n_h + query.numel() * n_node
+        mean = (sum_h + sum_q) / n
+        sq = sq_h + sq_q
+        metric["output_norm"] = sq.sqrt()
+        metric["output_mean"] = mean
+        metric["output_std"] = ((sq - mean * mean * n) / (n - 1)).clamp(min=0).sqrt()
 
     def _fused_score_ok(self, graph, t_index, metric):
         """The fused score head covers the shipped head (64-d hidden + 64-d query -> 128 -> 128 -> 1, relu),
