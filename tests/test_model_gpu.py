@@ -287,3 +287,48 @@ def test_grouped_relation_projection_equals_per_layer_path(batch, n_rel):
             assert table.shape == (n_rel, batch * 64) and torch.equal(table, want)
             ref = b(torch.relu(a(relation))).transpose(0, 1).flatten(1)
             torch.testing.assert_close(table, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_gradient_reducer_over_rccl_single_rank_group():
+    """The overlapped gradient all-reduce on the real backend: a ONE-rank `nccl` (= RCCL) process group on this GPU.
+    The reduction is the identity there, so three steps with the reducer (buckets launched from the backward hooks on a
+    side stream, compute stream waiting in finish()) must leave exactly the parameters of three plain steps -- and the
+    collectives really are issued (RCCL initialises, every bucket launches once per step)."""
+    import copy
+    import os
+    import torch.distributed as dist
+    from ultra_torchdrug_amd import engine
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        task, triples = _build("S-tiny")
+        task.num_negative = 16
+        dev = torch.device("cuda:0")
+        task.to(dev).train()
+        state = copy.deepcopy(task.state_dict())
+        batches = [torch.from_numpy(triples[i:i + 8]).to(dev) for i in (0, 8, 16)]
+        finals = {}
+        for mode in ("plain", "reducer"):
+            task.load_state_dict(state)
+            opt = torch.optim.AdamW(task.parameters(), lr=1e-3)
+            reducer = engine.GradientReducer(task, overlap=True, single_rank=True) if mode == "reducer" else None
+            launched = []
+            if reducer is not None:
+                real = reducer._launch
+                reducer._launch = lambda b: (launched.append(b), real(b))[1]
+            for b in batches:
+                torch.manual_seed(int(b[0, 0]))
+                engine.train_step(task, opt, b, reducer=reducer)
+            torch.cuda.synchronize()
+            finals[mode] = [p.detach().clone() for p in task.parameters()]
+            if reducer is not None:
+                assert launched == list(range(len(reducer.buckets))) * len(batches)      # bucket order, every step
+                assert reducer._side is not None                                            # a side stream was used
+                reducer.remove_hooks()
+        for a, b in zip(finals["plain"], finals["reducer"]):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()

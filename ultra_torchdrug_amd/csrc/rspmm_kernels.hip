@@ -34,7 +34,10 @@ thread_local int ultra_detail_last_hip_error = 0;
 namespace {
 
 constexpr int kTile = 64;            // columns per tile == wave width
-constexpr int kBlock = 1024;         // threads per workgroup (16 waves, 4 per SIMD)
+#ifndef ULTRA_BLOCK
+#define ULTRA_BLOCK 1024
+#endif
+constexpr int kBlock = ULTRA_BLOCK;   // threads per workgroup (1024: 16 waves, 4 per SIMD, 128 VGPRs each)
 constexpr int kWaves = kBlock / 64;
 #ifndef ULTRA_UNROLL
 #define ULTRA_UNROLL 8

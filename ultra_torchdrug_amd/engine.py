@@ -230,8 +230,11 @@ class GradientReducer:
     for the side stream and unpacks the averaged gradients; it must run before ``optimizer.step()``.
     Parameters that never receive a gradient (``UNUSED_PARAMETER_MARKS``) are excluded statically."""
 
-    def __init__(self, module, average=True, overlap=True):
+    def __init__(self, module, average=True, overlap=True, single_rank=False):
+        """``single_rank``: issue the collectives even in a one-rank group (a one-GPU box can then exercise the RCCL
+        path -- streams, hooks, packing -- end to end; the reduction itself is the identity there)."""
         self.module, self.average, self.overlap = module, average, overlap
+        self.single_rank = single_rank
         named = [(k, p) for k, p in module.named_parameters()
                  if p.requires_grad and not any(mark in k for mark in UNUSED_PARAMETER_MARKS)]
 
@@ -275,8 +278,11 @@ class GradientReducer:
         self._handles = []
 
     # ------------------------------------------------------------------ hooks (autograd thread, during backward)
+    def _active(self):
+        return dist.is_initialized() and (get_world_size() > 1 or self.single_rank)
+
     def _on_grad(self, param):
-        if get_world_size() == 1:
+        if not self._active():
             return
         b = self._bucket_of[id(param)]
         self._pending[b] -= 1
@@ -307,7 +313,7 @@ class GradientReducer:
         """Wait for every bucket (launching those whose hooks did not fire: ``overlap=False`` or a graph replay) and
         write the reduced gradients back.  Returns the number of fp32 elements reduced."""
         world = get_world_size()
-        if world == 1:
+        if not self._active():
             self._reset()
             return 0
         while self._next < len(self.buckets):                               # in bucket order, on every rank
