@@ -108,7 +108,8 @@ int ultra_rspmm_event_elapsed_ms(void *start_event, void *stop_event, float *ms_
 /* Test/bench knob (process-wide): bit 0 forces the general kernel where the packed fast paths apply, bit 1 keeps
  * them from staging a small gathered matrix in LDS, bit 2 selects one chunk per wave (packed_kernel) where four
  * chunks per wave (quad_kernel) would run, bit 3 the chunked kernels where one row per 16-lane group (rowgroup_kernel)
- * would run.  All paths return identical bits. */
+ * would run, bit 4 the wide-group forms of that kernel (32 / 64 lanes per row, column tiles of 128 / 256) on inputs small
+ * enough to be cache-resident.  All paths return identical bits. */
 int ultra_rspmm_force_general_path(int on);
 
 /* Scratch bytes a call over `seg` with row width F needs (piece partial sums). */

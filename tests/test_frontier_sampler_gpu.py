@@ -272,7 +272,7 @@ def test_rowgroup_kernel_and_raw_csr_entry_match_oracle(oracle, case):
     from ultra_torchdrug_amd import RelCSR, _lib, functional as UF
     dev = _dev()
     if case == "short_rows":
-        n, r, F = 3000, 40, 64
+        n, r, F = 3000, 40, 256
         g = random_graph(seed=5, n_node=n, n_edge=30000, n_rel=r)
     elif case == "weights_many_relations":
         n, r, F = 700, 900, 128          # relation tile does not fit LDS: rows through L2
@@ -304,8 +304,20 @@ def test_rowgroup_kernel_and_raw_csr_entry_match_oracle(oracle, case):
             raw = UF.rspmm_forward_csr(csr.fwd.row_ptr, csr.fwd.node_a[:csr.n_edges], csr.fwd.rel,
                                        None if csr.unit_weight else csr.weight, rel_t, x_t, s, m)
             assert np.array_equal(raw.cpu().numpy(), want), ("raw", s, m)
+    # wide groups (32 / 64 lanes per row: column tiles of 128 / 256, what big DRAM-resident inputs get): same bits
+    if F % 128 == 0:
+        lib.ultra_rspmm_force_general_path(16)
+        try:
+            for s in ("add", "max"):
+                wide = UF.rspmm_forward(csr, rel_t, x_t, s, "mul")
+                assert np.array_equal(wide.cpu().numpy(), oracle.rspmm_forward(csr_o, relation, x, s, "mul", piece=0)), s
+            d_x_w, _ = UF.rspmm_backward(csr, rel_t, x_t, None, g_t, "add", "mul", need_relation=False)
+        finally:
+            lib.ultra_rspmm_force_general_path(0)
+        d_x_n, _ = UF.rspmm_backward(csr, rel_t, x_t, None, g_t, "add", "mul", need_relation=False)
+        assert torch.equal(d_x_w, d_x_n)
     # fused boundary epilogues ride along as in the chunked kernels
-    node = torch.tensor([1, 17, 3][:F // 64], dtype=torch.int32, device=dev)
+    node = torch.tensor([1, 17, 3, 9][:F // 64], dtype=torch.int32, device=dev)
     value = torch.randn(F // 64, 64, device=dev)
     with_b = UF.rspmm_forward(csr, rel_t, x_t, "add", "mul", boundary=(node, value))
     lib.ultra_rspmm_force_general_path(8)

@@ -838,6 +838,7 @@ thread_local hipEvent_t g_prof_stop = nullptr;
 bool g_force_general = false;
 bool g_no_x_lds = false;
 bool g_no_quad = false;
+bool g_wide_groups = false;
 #ifndef ULTRA_QUAD_U
 #define ULTRA_QUAD_U 8
 #endif
@@ -1056,11 +1057,12 @@ int launch_quad(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_ld
     return ULTRA_ERR_BAD_OP;
 }
 
-// rowgroup_kernel dispatch.  backward: the d_input contribution order; needs_rel: a relation operand exists.
-template <int SUM, int MUL, bool BACKWARD>
+// rowgroup_kernel dispatch.  backward: the d_input contribution order; needs_rel: a relation operand exists; group:
+// lanes per row (16 / 32 / 64 -> column tiles of 64 / 128 / 256).
+template <int SUM, int MUL, bool BACKWARD, int G>
 int launch_rowgroup_w(const RowGroupParams &p, bool unit_w, bool rel_lds, bool needs_rel, int grid, size_t lds,
                       hipStream_t stream) {
-#define ULTRA_RG(UW, RL, NR) return launch_with_lds(rowgroup_kernel<SUM, MUL, UW, RL, NR, BACKWARD>, p, grid, lds, stream, kRgBlock)
+#define ULTRA_RG(UW, RL, NR) return launch_with_lds(rowgroup_kernel<SUM, MUL, UW, RL, NR, BACKWARD, G>, p, grid, lds, stream, kRgBlock)
     if (!needs_rel) {
         if (unit_w) ULTRA_RG(true, false, false);
         ULTRA_RG(false, false, false);
@@ -1074,15 +1076,16 @@ int launch_rowgroup_w(const RowGroupParams &p, bool unit_w, bool rel_lds, bool n
 #undef ULTRA_RG
 }
 
-int launch_rowgroup(const RowGroupParams &p, bool backward, int sum_op, int mul_op, bool unit_w, bool rel_lds, int grid,
-                    size_t lds, hipStream_t stream) {
+template <int G>
+int launch_rowgroup_g(const RowGroupParams &p, bool backward, int sum_op, int mul_op, bool unit_w, bool rel_lds, int grid,
+                      size_t lds, hipStream_t stream) {
     if (backward) {       // d_input of sum-aggregation: the relation operand exists only for mul = mul
         if (mul_op == ULTRA_MUL_MUL)
-            return launch_rowgroup_w<ULTRA_SUM_ADD, ULTRA_MUL_MUL, true>(p, unit_w, rel_lds, true, grid, lds, stream);
-        return launch_rowgroup_w<ULTRA_SUM_ADD, ULTRA_MUL_ADD, true>(p, unit_w, false, false, grid, kLdsHeader, stream);
+            return launch_rowgroup_w<ULTRA_SUM_ADD, ULTRA_MUL_MUL, true, G>(p, unit_w, rel_lds, true, grid, lds, stream);
+        return launch_rowgroup_w<ULTRA_SUM_ADD, ULTRA_MUL_ADD, true, G>(p, unit_w, false, false, grid, kLdsHeader, stream);
     }
 #define ULTRA_RCASE(S, M) \
-    if (sum_op == S && mul_op == M) return launch_rowgroup_w<S, M, false>(p, unit_w, rel_lds, true, grid, lds, stream);
+    if (sum_op == S && mul_op == M) return launch_rowgroup_w<S, M, false, G>(p, unit_w, rel_lds, true, grid, lds, stream);
     ULTRA_RCASE(ULTRA_SUM_ADD, ULTRA_MUL_MUL)
     ULTRA_RCASE(ULTRA_SUM_ADD, ULTRA_MUL_ADD)
     ULTRA_RCASE(ULTRA_SUM_MIN, ULTRA_MUL_MUL)
@@ -1091,6 +1094,27 @@ int launch_rowgroup(const RowGroupParams &p, bool backward, int sum_op, int mul_
     ULTRA_RCASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
 #undef ULTRA_RCASE
     return ULTRA_ERR_BAD_OP;
+}
+
+// Fills the tiling fields of `q` and launches.  Wide groups only where the gathered matrix cannot be cache-resident
+// (beyond the 256 MB Infinity Cache): there one contiguous fetch per edge beats L2 locality of 64-column tiles.
+int launch_rowgroup(RowGroupParams &q, bool backward, int sum_op, int mul_op, bool unit_w, long long gather_rows, int n_cu,
+                    hipStream_t stream) {
+    const long long F = q.F;
+    const bool dram = g_wide_groups || (double)gather_rows * (double)F * 4.0 > 256.0 * 1024 * 1024;
+    const int group = (dram && F % 256 == 0) ? 64 : ((dram && F % 128 == 0) ? 32 : 16);
+    const int width = 4 * group;
+    q.n_tiles = (int)((F + width - 1) / width);
+    q.split = kXcd / gcd_int(q.n_tiles, kXcd);
+    q.n_slots = q.n_tiles * q.split;
+    q.blocks_per_label = (n_cu + kXcd - 1) / kXcd;
+    const size_t lds_need = (size_t)q.n_rel * width * sizeof(float);
+    const bool rel_fits = q.n_rel > 0 && lds_need <= (size_t)kMaxLdsBytes;
+    const int grid = q.blocks_per_label * kXcd;
+    const size_t lds = kLdsHeader + (rel_fits ? lds_need : 0);
+    if (group == 64) return launch_rowgroup_g<64>(q, backward, sum_op, mul_op, unit_w, rel_fits, grid, lds, stream);
+    if (group == 32) return launch_rowgroup_g<32>(q, backward, sum_op, mul_op, unit_w, rel_fits, grid, lds, stream);
+    return launch_rowgroup_g<16>(q, backward, sum_op, mul_op, unit_w, rel_fits, grid, lds, stream);
 }
 
 bool g_no_rowgroup = false;
@@ -1172,13 +1196,7 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
             q.F = F;
             q.n_rows = (int)seg->n_rows;
             q.n_rel = (int)n_rel;
-            q.n_tiles = n_tiles;
-            q.split = split;
-            q.n_slots = p.n_slots;
-            q.blocks_per_label = blocks_per_label;
-            const bool rel_fits = n_rel > 0 && lds_need <= (size_t)kMaxLdsBytes;
-            rc = launch_rowgroup(q, KIND == KIND_DX, sum_op, mul_op, seg->weight == nullptr, rel_fits, grid,
-                                 kLdsHeader + (rel_fits ? lds_need : 0), stream);
+            rc = launch_rowgroup(q, KIND == KIND_DX, sum_op, mul_op, seg->weight == nullptr, gather_rows, di->n_cu, stream);
             if (rc) return rc;
         }
     }
@@ -1333,6 +1351,7 @@ int ultra_rspmm_force_general_path(int on) {
     g_no_x_lds = (on & 2) != 0;           // bit 1: packed kernel without staging the gathered matrix in LDS
     g_no_quad = (on & 4) != 0;            // bit 2: one chunk per wave (packed_kernel) instead of four (quad_kernel)
     g_no_rowgroup = (on & 8) != 0;        // bit 3: chunked kernels where one row per group (rowgroup_kernel) would run
+    g_wide_groups = (on & 16) != 0;       // bit 4: rowgroup_kernel with 32 / 64 lanes per row even for cache-sized inputs
     return ULTRA_OK;
 }
 
@@ -1408,14 +1427,8 @@ int ultra_rspmm_fwd_f32(const int32_t *row_ptr, const int32_t *src, const int32_
     q.F = F;
     q.n_rows = (int)N;
     q.n_rel = (int)R;
-    q.n_tiles = (int)((F + kTile - 1) / kTile);
-    q.split = kXcd / gcd_int(q.n_tiles, kXcd);
-    q.n_slots = q.n_tiles * q.split;
-    q.blocks_per_label = (di->n_cu + kXcd - 1) / kXcd;
-    const size_t lds_need = (size_t)R * kTile * sizeof(float);
-    const bool rel_fits = R > 0 && lds_need <= (size_t)kMaxLdsBytes;
-    return launch_rowgroup(q, false, sum_op, mul_op, w == nullptr, rel_fits, q.blocks_per_label * kXcd,
-                           kLdsHeader + (rel_fits ? lds_need : 0), static_cast<hipStream_t>(stream));
+    // (the rows of x are not part of this signature; N stands in for them in the cache-residency heuristic)
+    return launch_rowgroup(q, false, sum_op, mul_op, w == nullptr, N, di->n_cu, static_cast<hipStream_t>(stream));
 }
 
 int ultra_rspmm_forward_boundary_f32(const ultra_segments *fwd, const float *relation, const float *input,
