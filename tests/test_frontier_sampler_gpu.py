@@ -264,7 +264,7 @@ def test_graphed_train_step_captures_negatives_and_edge_removal():
 
 
 # ------------------------------------------------------------------------------------------------ rowgroup / raw CSR
-@pytest.mark.parametrize("case", ["short_rows", "weights_many_relations", "ragged_with_empty_rows"])
+@pytest.mark.parametrize("case", ["short_rows", "weights_many_relations", "relations_beyond_lds", "ragged_with_empty_rows"])
 def test_rowgroup_kernel_and_raw_csr_entry_match_oracle(oracle, case):
     """One row per 16-lane group (csrc/rowgroup.inc): (i) as the kernel run_plan picks for big-graph plans without split
     rows (forced on small graphs with wide_ids=True), against the chunked kernels (knob bit 3) and the oracle; (ii) as
@@ -275,8 +275,11 @@ def test_rowgroup_kernel_and_raw_csr_entry_match_oracle(oracle, case):
         n, r, F = 3000, 40, 256
         g = random_graph(seed=5, n_node=n, n_edge=30000, n_rel=r)
     elif case == "weights_many_relations":
-        n, r, F = 700, 900, 128          # relation tile does not fit LDS: rows through L2
+        n, r, F = 700, 900, 128          # relation table beyond LDS: its first 624 / 312 rows from LDS, the rest through L2
         g = random_graph(seed=6, n_node=n, n_edge=9000, n_rel=r, weights=True)
+    elif case == "relations_beyond_lds":
+        n, r, F = 400, 700, 256          # 64-lane groups hold 156 of 700 relation rows: below a quarter, all rows through L2
+        g = random_graph(seed=8, n_node=n, n_edge=5000, n_rel=r)
     else:
         n, r, F = 500, 5, 192
         g = random_graph(seed=7, n_node=n, n_edge=6000, n_rel=r, isolated=120, hub_row=9, hub_edges=100)

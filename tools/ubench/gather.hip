@@ -43,6 +43,7 @@ __global__ __launch_bounds__(kBlock) void gather_a(const float* tab, const int* 
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
+template <int AUX>
 __global__ __launch_bounds__(kBlock) void gather_b(const float* tab, const int* idx, float* out) {
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, j = lane & 15;
@@ -56,7 +57,29 @@ __global__ __launch_bounds__(kBlock) void gather_b(const float* tab, const int* 
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int row = __shfl(mine, u * 4 + q, 64);
-            v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, row * (kRowStride * 4) + j * 16, 0, 0);
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, row * (kRowStride * 4) + j * 16, 0, AUX);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += __builtin_bit_cast(float, v[u].x) + __builtin_bit_cast(float, v[u].y) + __builtin_bit_cast(float, v[u].z) + __builtin_bit_cast(float, v[u].w);
+    }
+    out[(size_t)wave * 64 + lane] = acc;
+}
+
+// H: eight 128-B half rows per wave-instruction (8 lanes x 16 B each): what a 32-column tile would gather
+__global__ __launch_bounds__(kBlock) void gather_h(const float* tab, const int* idx, float* out, int half) {
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 3, j = lane & 7;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const int* my = idx + (size_t)wave * kPerWave;
+    const char* base = (const char*)tab + half * 128 + j * 16;
+    float acc = 0;
+    for (int i = 0; i < kPerWave; i += 64) {
+        uint4v v[8];
+        const unsigned mine = (unsigned)my[i + lane] >> kShift;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned row = (unsigned)__shfl((int)mine, u * 8 + q, 64);
+            v[u] = *(const uint4v*)(base + (unsigned long long)row * (kRowStride * 4));
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += __builtin_bit_cast(float, v[u].x) + __builtin_bit_cast(float, v[u].y) + __builtin_bit_cast(float, v[u].z) + __builtin_bit_cast(float, v[u].w);
@@ -177,11 +200,38 @@ int main() {
     float* rows; hipMalloc(&rows, (size_t)kRows * kRowStride * 4);
     hipFuncSetAttribute((const void*)gather_a2, hipFuncAttributeMaxDynamicSharedMemorySize, 474 * 256);
     hipFuncSetAttribute((const void*)gather_a3, hipFuncAttributeMaxDynamicSharedMemorySize, 474 * 256);
+    for (int pol = 0; pol < 7; ++pol) {     // cache policy bits of the gather: 1 = sc0, 2 = nt, 16 = sc1
+        const int aux[7] = {0, 1, 2, 3, 16, 17, 18};
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(a);
+            switch (pol) {
+                case 0: hipLaunchKernelGGL(gather_b<0>, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out); break;
+                case 1: hipLaunchKernelGGL(gather_b<1>, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out); break;
+                case 2: hipLaunchKernelGGL(gather_b<2>, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out); break;
+                case 3: hipLaunchKernelGGL(gather_b<3>, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out); break;
+                case 4: hipLaunchKernelGGL(gather_b<16>, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out); break;
+                case 5: hipLaunchKernelGGL(gather_b<17>, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out); break;
+                case 6: hipLaunchKernelGGL(gather_b<18>, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out); break;
+            }
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (rep == 2) printf("dwordx4 gather, cache policy aux=%d: %.3f ms  %.2f TB/s  %.1f GB/s/CU (%s)\n", aux[pol], ms, bytes / ms / 1e9, bytes / ms / 1e6 / n_cu, hipGetErrorString(hipGetLastError()));
+        }
+    }
+    for (int half = 0; half < 2; ++half) {
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL(gather_h, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out, half);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (rep == 2) printf("variant H (128-B half rows, half %d): %.3f ms  %.2f TB/s of requested bytes (%s)\n", half, ms, bytes / 2 / ms / 1e9, hipGetErrorString(hipGetLastError()));
+        }
+    }
     for (int which = 0; which < 5; ++which) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(a);
             if (which == 0) hipLaunchKernelGGL(gather_a, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
-            if (which == 1) hipLaunchKernelGGL(gather_b, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
+            if (which == 1) hipLaunchKernelGGL(gather_b<0>, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
             if (which == 2) hipLaunchKernelGGL(gather_c, dim3(blocks), dim3(kBlock), 0, 0, tab, idx, out);
             if (which == 3) hipLaunchKernelGGL(gather_a2, dim3(blocks), dim3(kBlock), 474 * 256, 0, tab, idx, out);
             if (which == 4) hipLaunchKernelGGL(gather_a3, dim3(blocks), dim3(kBlock), 474 * 256, 0, tab, idx, desc, out, rows);
