@@ -165,7 +165,7 @@ def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel
         lib.ultra_rspmm_force_general_path(0)
     E = csr.n_edges
     algo = bytes_algo(E, n_node, R, F)
-    kernel = "rowgroup_kernel<add,mul,unit_w,rel via L2>" if plan.row_ptr is not None and plan.n_pieces == 0 \
+    kernel = "rowgroup_kernel<add,mul,unit_w,624 of 1000 relation rows from LDS>" if plan.row_ptr is not None and plan.n_pieces == 0 \
         else "packed_kernel<FWD,add,mul,unit_w,VAR 2>"
     return {"bound": "hbm", "workload": "S-stress N=%d E=%d R=%d B=1 F=64 (input %.2f GB)" % (n_node, E, R, n_node * F * 4 / 1e9),
             "kernel": kernel, "launches_timed": n, "kernel_ms": ms, "algorithmic_bytes": algo,

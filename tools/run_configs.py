@@ -52,7 +52,7 @@ def main():
         cfgs.append(("Synthetic 10M nodes / 100M edges (config 5)", "S-stress", 1, False))
     threads = len(os.sched_getaffinity(0))
     os.environ["OMP_NUM_THREADS"] = str(threads)
-    print("| config | N | E | R | B | fwd us | fwd edge-msgs/s | fwd algorithmic GB/s (fraction of the bounding peak: 34.5 TB/s XCD-L2 when the gathered matrix fits the 256 MB Infinity Cache, 8 TB/s HBM otherwise) | bwd us (d_input + d_relation) | CPU port fwd edge-msgs/s (%d cores) |" % threads)
+    print("| config | N | E | R | B | fwd us | fwd edge-msgs/s | fwd algorithmic GB/s (fraction of the bounding peak: 34.5 TB/s XCD-L2 when the slice of the gathered matrix one 64-column tile touches, N x 256 B, is cache-resident (<= 32 MB: an XCD's L2 plus its share of the Infinity Cache; the kernels walk the graph tile by tile), 8 TB/s HBM otherwise) | bwd us (d_input + d_relation) | CPU port fwd edge-msgs/s (%d cores) |" % threads)
     print("|---|---|---|---|---|---|---|---|---|---|")
     for name, wl, B, bwd in cfgs:
         g = synthetic_kg(wl, device=dev).undirected(add_inverse=True)
@@ -78,7 +78,7 @@ def main():
                 t0 = time.perf_counter(); O.rspmm_forward(co, rc, xc); ts.append(time.perf_counter() - t0)
             cpu = "%.2e" % (E * (Fc // 64) / float(np.median(ts)))
         print("| %s | %d | %d | %d | %d | %.1f | %.2e | %.0f (%.2f) | %s | %s |" % (
-            name, N, E, R, B, t_f, E * B / (t_f * 1e-6), algo / t_f / 1e3, algo / t_f / 1e3 / (34500 if N * F * 4 < 256e6 else 8000),
+            name, N, E, R, B, t_f, E * B / (t_f * 1e-6), algo / t_f / 1e3, algo / t_f / 1e3 / (34500 if N * 256 <= 32e6 else 8000),
             "%.1f" % t_b if t_b else "-", cpu))
         del g, csr, rel, x
         torch.cuda.empty_cache()
