@@ -1024,7 +1024,7 @@ int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, int var
 
 template <int KIND, int SUM, int MUL>
 int launch_quad_w(const PParams &p, bool unit_w, bool x_lds, int grid, size_t lds, hipStream_t stream) {
-    if constexpr (KIND != KIND_DREL) {
+    if constexpr (KIND != KIND_DREL || MUL == ULTRA_MUL_MUL) {       // d_relation of mul = add reads no `input` row
         if (x_lds) {
             if (unit_w) return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, true, kQuadUX>, p, grid, lds, stream);
             return launch_with_lds(quad_kernel<KIND, SUM, MUL, false, true, kQuadUW>, p, grid, lds, stream);
@@ -1051,7 +1051,7 @@ int launch_quad(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_ld
         if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream);
         return launch_quad_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, x_lds, grid, lds, stream);
     } else {
-        if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, false, grid, kLdsHeader, stream);
+        if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream);
         return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, false, grid, kLdsHeader, stream);
     }
     return ULTRA_ERR_BAD_OP;
@@ -1274,9 +1274,9 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
                 lds_bytes += hot_bytes;
                 q.hot_nodes = seg->hot_nodes;
                 q.n_hot = (int)seg->n_hot;
-            } else if ((KIND != KIND_DREL) && !g_no_x_lds && gather_rows > 0 &&
+            } else if ((KIND != KIND_DREL || mul_op == ULTRA_MUL_MUL) && !g_no_x_lds && gather_rows > 0 &&
                        lds_bytes + lds_x_bytes <= (size_t)kMaxLdsBytes) {
-                var = 1;
+                var = 1;       // d_relation: the `input` rows (picked by source node) from LDS, output_grad stays a gather
                 lds_bytes += lds_x_bytes;
             }
             q.n_gather_rows = (int)gather_rows;
