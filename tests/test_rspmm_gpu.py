@@ -364,6 +364,52 @@ def test_backward_kernels_agree(oracle, case):
                     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case", ["skewed_hub", "small_weights", "isolated_and_ragged_F", "short_rows_wn18rr_like"])
+def test_backward_accumulates_into_the_given_gradient(case):
+    """``rspmm_backward(..., d_input_add=A)`` (ultra_rspmm_backward_accumulate_f32: the edge gradient lands IN ``A``, as
+    the training layer node uses it) == ``A + rspmm_backward(...)`` bit for bit -- one fp32 addition per element either
+    way -- with every kernel family: quad (fire-and-forget fp32 atomics in the row epilogue), packed, general, and the
+    row-per-group kernel of wide-id plans.  Split hub rows (fixup_kernel adds), empty rows (A + 0) and rows ending every
+    few edges included; ``d_relation`` must not change."""
+    import ultra_torchdrug_amd as U
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    if case == "short_rows_wn18rr_like":
+        n, r, F = 5000, 22, 256
+        g = random_graph(seed=80, n_node=n, n_rel=r, n_edge=21000, skew=False)
+    else:
+        kw, n, r, F = CASES[case]
+        g = random_graph(seed=78, n_node=n, n_rel=r, **kw)
+    relation, x = _inputs(7, n, r, F)
+    rng = np.random.default_rng(81)
+    grad = rng.standard_normal((n, F)).astype(np.float32)
+    base = rng.standard_normal((n, F)).astype(np.float32)
+    base[::7] = 0.0                                             # rows of exact zeros (and -0.0) in the accumulator
+    base[3::11] = -0.0
+    dev = _dev()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    lib = U.require_library()
+    plans = [_relcsr(g, n, n, r)]
+    if F % 4 == 0:
+        plans.append(RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), None if g["w"] is None else t(g["w"]), n, n, r,
+                            wide_ids=True))
+    for csr in plans:
+        for m in MULS:
+            for flags in (0, 4, 1):
+                lib.ultra_rspmm_force_general_path(flags)
+                try:
+                    plain_x, plain_r = UF.rspmm_backward(csr, t(relation), t(x), None, t(grad), "add", m)
+                    acc = t(base).clone()
+                    got_x, got_r = UF.rspmm_backward(csr, t(relation), t(x), None, t(grad), "add", m, d_input_add=acc)
+                finally:
+                    lib.ultra_rspmm_force_general_path(0)
+                assert got_x.data_ptr() == acc.data_ptr()                  # in place
+                want = t(base) + plain_x
+                assert torch.equal(got_x, want), (m, flags)
+                assert got_x.view(torch.int32).eq(want.view(torch.int32)).all() or \
+                    bool(((got_x == 0) & (want == 0))[got_x.view(torch.int32) != want.view(torch.int32)].all())
+                assert torch.equal(got_r, plain_r), (m, flags)
+
+
 @pytest.mark.parametrize("rows", [1, 31, 32, 33, 4096 + 17, 14541 * 16])
 @pytest.mark.parametrize("ln,relu,shortcut", [(True, True, True), (False, True, False), (True, False, True)])
 def test_fused_combine_matches_oracle_and_torch(oracle, rows, ln, relu, shortcut):
