@@ -38,7 +38,6 @@ constexpr int kTile = 64;            // columns per tile == wave width
 #define ULTRA_BLOCK 1024
 #endif
 constexpr int kBlock = ULTRA_BLOCK;   // threads per workgroup (1024: 16 waves, 4 per SIMD, 128 VGPRs each)
-constexpr int kWaves = kBlock / 64;
 #ifndef ULTRA_UNROLL
 #define ULTRA_UNROLL 8
 #endif
