@@ -422,8 +422,17 @@ def main():
     mrr_check = []
     train_ms = None
     if args.mrr_queries > 0:
-        nq = min(args.mrr_queries, len(shard))
-        metrics = metrics_of(mrr_of(task, shard[:nq]))
+        # the seeded test triples are strided over the ranks; one all_gather of (n, 2) int64 ranks
+        nq = min(-(-args.mrr_queries // world), len(test) // world)       # the same count on every rank
+
+        def gathered(ranks):
+            if world == 1:
+                return ranks
+            parts = [torch.empty_like(ranks) for _ in range(world)]
+            dist.all_gather(parts, ranks)
+            return torch.cat(parts)
+
+        metrics = metrics_of(gathered(mrr_of(task, shard[:nq])))
         mrr = metrics["mrr"]
         check = rank == 0 and world == 1 and not args.no_cpu_baseline
         if check:
@@ -452,7 +461,7 @@ def main():
             train_ms = 1e3 * (time.perf_counter() - t1) / args.finetune_steps
             del graphed_step
             task.eval()
-            metrics_tuned = metrics_of(mrr_of(task, shard[:nq]))
+            metrics_tuned = metrics_of(gathered(mrr_of(task, shard[:nq])))
             mrr_tuned = metrics_tuned["mrr"]
             if check:
                 mrr_check.append(oracle_check("after %d seeded fine-tuning steps on the HIP path" % args.finetune_steps))
@@ -470,7 +479,9 @@ def main():
             "config": {"workload": "%s N=%d E=%d R=%d B=%d F=%d, 6+6 layers x 64d, predict() tail+head over all "
                                    "entities (E_rel=%d)" % (args.workload, n_node, E, R2, B, F, E_rel),
                        "global_batch": B * world, "parallelism": "query-sharded replicas x%d" % world,
-                       "launch": "eager" if graphed is None else "one hipGraph replay per step (engine.GraphedPredict)"},
+                       "launch": "eager" if graphed is None else "one hipGraph replay per step (engine.GraphedPredict)",
+                       "device": "%s, %d CUs" % (torch.cuda.get_device_name(dev),
+                                                 torch.cuda.get_device_properties(dev).multi_processor_count)},
             "edges_per_step": edges_per_step,
             "composition": {
                 "entity_graph_edges_per_step": entity_edges_per_step,
