@@ -428,6 +428,7 @@ def main():
         def gathered(ranks):
             if world == 1:
                 return ranks
+            ranks = ranks.cpu() if share else ranks            # (development switch: gloo works on host tensors)
             parts = [torch.empty_like(ranks) for _ in range(world)]
             dist.all_gather(parts, ranks)
             return torch.cat(parts)

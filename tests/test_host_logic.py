@@ -418,3 +418,19 @@ def test_missing_library_fails_loudly():
     env = dict(os.environ, ULTRA_RSPMM_LIB="/nonexistent/libultra_rspmm.so", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "RAISED UltraLibraryError" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_byte_model_is_the_surveys():
+    """bench.py's algorithmic / compulsory byte formulas are SURVEY.md 8d's, at the sizes VERDICT r1 recomputed by hand:
+    S-fb15k237, F = 2048 (tails and heads of 16 queries in one launch): 4.588 GB algorithmic, 248.7 MB compulsory;
+    S-stress, B = 1: 29.4 GB per layer."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    E, N, R, F = 544_230, 14_541, 474, 2048
+    assert bench.bytes_algo(E, N, R, F) == 544_230 * (4 * 2048 + 12) + 4 * 14_541 * 2048 + 4 * 474 * 2048 + 4 * 14_542
+    assert abs(bench.bytes_algo(E, N, R, F) / 1e9 - 4.588) < 5e-4
+    assert abs(bench.bytes_min(E, N, R, F) / 1e6 - 248.7) < 0.05
+    assert abs(bench.bytes_algo(100_000_000, 10_000_000, 1000, 64) / 1e9 - 29.4) < 0.05
