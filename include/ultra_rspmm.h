@@ -292,6 +292,24 @@ int ultra_relation_project_f32(const float *relation, const float *const *w1, co
                                const float *const *w2, const float *const *b2, float *const *out, int64_t n_layers,
                                int64_t batch, int64_t n_rel, int64_t dim, void *stream);
 
+/* Backward of ultra_relation_project_f32 for all layers in one launch (training):
+ *     d_w1[l], d_b1[l], d_w2[l], d_b2[l]   gradients of the layer's four parameters ([64, 64] / [64], overwritten)
+ *     d_relation_layers[l, b * n_rel + r, :]   the layer's gradient of relation[b, r, :]; the input feeds every layer,
+ *                                              so the caller sums over l
+ * from grad[l] = the gradient of out[l] ([n_rel, batch, 64]; a NULL entry = no gradient reached that table: zeros).
+ * Replaces the autograd chain of 2 x n_layers nn.Linear + relu + transpose the reference runs for
+ * `relation_projection` (ultra/layer.py:228,318-319,325-326): 6 GEMMs + 2 bias reductions + elementwise passes per
+ * layer.  The hidden activation is recomputed with the forward kernel's chain.  n_layers <= 8.
+ *   w1 / b1 / w2 / grad / d_w1 / d_b1 / d_w2 / d_b2 : HOST arrays of n_layers DEVICE pointers.
+ *   workspace : device scratch of n_layers * blocks * (2 * 64 * 64 + 128) floats, `blocks` from
+ *   ultra_relation_project_backward_blocks (depends on the device's CU count and the shape only). */
+int ultra_relation_project_backward_blocks(int device, int64_t batch, int64_t n_rel, int64_t n_layers, int64_t *blocks);
+int ultra_relation_project_backward_f32(const float *relation, const float *const *w1, const float *const *b1,
+                                        const float *const *w2, const float *const *grad, float *d_relation_layers,
+                                        float *const *d_w1, float *const *d_b1, float *const *d_w2, float *const *d_b2,
+                                        void *workspace, size_t workspace_bytes, int64_t n_layers, int64_t batch,
+                                        int64_t n_rel, int64_t dim, void *stream);
+
 /* Filtered ranking on the device, from filter LISTS instead of dense masks.
  * Replaces: get_ranking, ultra/task.py:307-315 -- `sum((pos_pred <= pred) & mask, -1) + 1` -- together with the dense
  * (B, N) boolean masks of ultra/task.py:65-100 (`mask[pos_index, truth_index] = 0`) that feed it.

@@ -137,6 +137,12 @@ class OracleFunctional:
         return outs
 
     @staticmethod
+    def relation_project_train(relation, weights):
+        """The reference's own chain with autograd (layer.py:318-319,325-326): the yardstick of the one-launch backward."""
+        import torch.nn.functional as F
+        return [F.linear(F.relu(F.linear(relation, w1, b1)), w2, b2).transpose(0, 1).flatten(1) for w1, b1, w2, b2 in weights]
+
+    @staticmethod
     def remove_triples(graph, h, t, r, n_base_rel):
         """model.py:57-74 + :166 on the graph with inverse edges: weight 0 for (h, t, r) and (t, h, r + R)."""
         n, rels = graph.num_node, graph.num_relation

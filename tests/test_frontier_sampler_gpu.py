@@ -370,3 +370,52 @@ def test_one_pass_combine_backward_equals_three_kernel_backward(monkeypatch, row
         else:
             scale = b.abs().max().item() + 1e-12
             assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-6, name
+
+
+# ------------------------------------------------------------------------------------------------ grouped projections, training
+@pytest.mark.parametrize("batch,n_rel,n_layers", [(3, 5, 1), (16, 22, 6), (16, 474, 6), (64, 102, 8), (1, 1, 2)])
+def test_grouped_relation_projection_backward_matches_autograd_of_the_reference_chain(batch, n_rel, n_layers):
+    """functional.relation_project_train (csrc/project_bwd.inc): forward = the inference tables bit for bit; backward =
+    one launch for the gradients of all layers' four parameters and of the relation representations, against fp64
+    autograd of the reference's own chain -- nn.Linear, relu, nn.Linear, transpose (ultra/layer.py:318-319,325-326) --
+    to 2e-5 of each gradient's scale (the bar of the fused epilogue's backward).  One layer's table receives no gradient
+    at all (a NULL entry of the C call)."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = _dev()
+    gen = torch.Generator(device=dev).manual_seed(batch * 1000 + n_rel)
+    relation = torch.randn(batch, n_rel, 64, device=dev, generator=gen)
+    weights = []
+    for _ in range(n_layers):
+        weights.append((torch.randn(64, 64, device=dev, generator=gen) * 0.2, torch.randn(64, device=dev, generator=gen) * 0.1,
+                        torch.randn(64, 64, device=dev, generator=gen) * 0.2, torch.randn(64, device=dev, generator=gen) * 0.1))
+    table_grads = [torch.randn(n_rel, batch * 64, device=dev, generator=gen) for _ in range(n_layers)]
+    unused = n_layers - 1 if n_layers > 1 else None
+
+    def run(dtype, fn):
+        x = relation.to(dtype).detach().clone().requires_grad_()
+        ws = [tuple(t.to(dtype).detach().clone().requires_grad_() for t in lw) for lw in weights]
+        tables = fn(x, ws)
+        loss = sum((t * g.to(dtype)).sum() for k, (t, g) in enumerate(zip(tables, table_grads)) if k != unused)
+        loss.backward()
+        return tables, x.grad, [[t.grad for t in lw] for lw in ws]
+
+    chain = lambda x, ws: [torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, w1, b1)), w2, b2)
+                           .transpose(0, 1).flatten(1) for w1, b1, w2, b2 in ws]
+    tables, d_x, d_w = run(torch.float32, UF.relation_project_train)
+    with torch.no_grad():
+        plain = UF.relation_project(relation, weights)
+    for a, b in zip(tables, plain):
+        assert torch.equal(a.detach(), b)
+    _, d_x64, d_w64 = run(torch.float64, chain)
+
+    def close(got, want, what):
+        scale = want.abs().max().item() + 1e-12
+        assert (got.double() - want).abs().max().item() <= 2e-5 * scale, what
+
+    close(d_x, d_x64, "d_relation")
+    for l in range(n_layers):
+        for k, name in enumerate(("w1", "b1", "w2", "b2")):
+            if l == unused:        # no gradient reached this layer: exact zeros
+                assert d_w[l][k] is None or not d_w[l][k].any(), (l, name)
+            else:
+                close(d_w[l][k], d_w64[l][k], (l, name))

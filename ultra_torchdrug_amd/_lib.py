@@ -66,6 +66,8 @@ EXPORTS = (
     "ultra_linear_forward_f32",
     "ultra_score_forward_f32",
     "ultra_relation_project_f32",
+    "ultra_relation_project_backward_blocks",
+    "ultra_relation_project_backward_f32",
     "ultra_filtered_rank",
     "ultra_filtered_rank_keys",
     "ultra_strict_negative",
@@ -156,6 +158,10 @@ def load():
     lib.ultra_score_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
     lib.ultra_relation_project_f32.restype = i32
     lib.ultra_relation_project_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]
+    lib.ultra_relation_project_backward_blocks.restype = i32
+    lib.ultra_relation_project_backward_blocks.argtypes = [i32, i64, i64, i64, vp]
+    lib.ultra_relation_project_backward_f32.restype = i32
+    lib.ultra_relation_project_backward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, vp]
     lib.ultra_filtered_rank.restype = i32
     lib.ultra_filtered_rank.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
     lib.ultra_filtered_rank_keys.restype = i32

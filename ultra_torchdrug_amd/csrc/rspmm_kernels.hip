@@ -1639,4 +1639,5 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
 #include "combine_train.inc"
 #include "combine_fused_bwd.inc"
 #include "dense.inc"
+#include "project_bwd.inc"
 #include "sampler.inc"

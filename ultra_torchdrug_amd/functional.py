@@ -354,6 +354,56 @@ def relation_project(relation, weights):
     return outs
 
 
+class _ProjectFunction(torch.autograd.Function):
+    """All layers' relation projections as ONE autograd node: forward = :func:`relation_project` (one launch, the
+    documented order, the tables inference uses), backward = ``ultra_relation_project_backward_f32`` (one launch + a
+    small reduction) instead of autograd through 2 L ``nn.Linear`` + relu + transposes (~100 launches of a few
+    microseconds per fine-tuning step)."""
+
+    @staticmethod
+    def forward(ctx, relation, *flat_weights):
+        weights = [tuple(flat_weights[4 * l:4 * l + 4]) for l in range(len(flat_weights) // 4)]
+        ctx.save_for_backward(relation, *flat_weights)
+        tables = relation_project(relation, weights)
+        return tuple(tables)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        relation, *flat_weights = ctx.saved_tensors
+        relation = relation.contiguous()
+        n = len(flat_weights) // 4
+        batch, n_rel, _ = relation.shape
+        dev = relation.device
+        keep = [None if g is None else g.contiguous() for g in grads]
+        w = [t.detach().contiguous() for t in flat_weights]
+        d_w = [torch.empty_like(t) for t in w]
+        d_layers = torch.empty(n, batch * n_rel, 64, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        blocks = ctypes.c_int64(0)
+        _lib.check(lib.ultra_relation_project_backward_blocks(dev.index or 0, batch, n_rel, n, ctypes.byref(blocks)))
+        ws = torch.empty(n * blocks.value * (2 * 64 * 64 + 128), dtype=torch.float32, device=dev)
+        arr = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_relation_project_backward_f32(
+                relation.data_ptr(), arr([w[4 * l].data_ptr() for l in range(n)]), arr([w[4 * l + 1].data_ptr() for l in range(n)]),
+                arr([w[4 * l + 2].data_ptr() for l in range(n)]), arr([None if g is None else g.data_ptr() for g in keep]),
+                d_layers.data_ptr(), arr([d_w[4 * l].data_ptr() for l in range(n)]), arr([d_w[4 * l + 1].data_ptr() for l in range(n)]),
+                arr([d_w[4 * l + 2].data_ptr() for l in range(n)]), arr([d_w[4 * l + 3].data_ptr() for l in range(n)]),
+                ws.data_ptr(), ws.numel() * 4, n, batch, n_rel, 64, _stream()))
+        d_relation = d_layers.sum(0).view(batch, n_rel, 64) if ctx.needs_input_grad[0] else None
+        return (d_relation, *[g if need else None for g, need in zip(d_w, ctx.needs_input_grad[1:])])
+
+
+def relation_project_train(relation, weights):
+    """:func:`relation_project` with gradients (``relation`` and the four parameters of every layer): the training form
+    of the grouped projections.  At most 8 layers per call (the kernels' parameter block)."""
+    if len(weights) > 8:
+        raise RuntimeError("relation_project_train: at most 8 layers per call")
+    flat = [t for layer_weights in weights for t in layer_weights]
+    return list(_ProjectFunction.apply(relation, *flat))
+
+
 def filtered_rank(pred, target, filt_ptr=None, filt_node=None):
     """``sum((pos_pred <= pred) & mask, -1) + 1`` (``ultra/task.py:307-315``) with the mask given as per-row lists of
     DISTINCT filtered candidates (``filt_ptr`` int32 ``(rows + 1,)``, ``filt_node`` int32) -- no dense ``(B, N)``

@@ -139,12 +139,14 @@ class TransferNBFNet(nn.Module):
         return {"node_feature": output, "step_graphs": step_graphs}
 
     def _relation_tables(self, batch_size):
-        """Inference on the GPU with per-query relation representations and the shipped 64 -> 64 -> 64 projections:
-        the ``(R, B * D)`` relation tables of ALL layers from one launch (each layer otherwise issues two linear
-        launches and a transposing copy of its own, layer.py:318-326).  ``None``: every layer builds its own."""
+        """On the GPU with per-query relation representations and the shipped 64 -> 64 -> 64 projections: the
+        ``(R, B * D)`` relation tables of ALL layers from one launch (each layer otherwise issues two linear launches
+        and a transposing copy of its own, layer.py:318-326) -- in training as one autograd node whose backward is
+        one launch too (``relation_project_train``).  ``None``: every layer builds its own."""
         ops = backend.get()
         convs = list(self.layers)
-        if torch.is_grad_enabled() or not convs:
+        training = torch.is_grad_enabled()
+        if not convs or (training and len(convs) > 8):
             return None
         relation = getattr(convs[0], "relation", None)
         if relation is None or not ops.accepts(relation) or relation.dim() != 3 or relation.shape[0] != batch_size \
@@ -159,7 +161,7 @@ class TransferNBFNet(nn.Module):
             if not ok:
                 return None
             weights.append((mlp.layers[0].weight, mlp.layers[0].bias, mlp.layers[1].weight, mlp.layers[1].bias))
-        tables = ops.relation_project(relation, weights)
+        tables = ops.relation_project_train(relation, weights) if training else ops.relation_project(relation, weights)
         return {id(conv): table for conv, table in zip(convs, tables)}
 
     def score_all_entities(self, graph, rel_query_list, h_index, r_index):
