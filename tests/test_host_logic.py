@@ -434,3 +434,37 @@ def test_bench_byte_model_is_the_surveys():
     assert abs(bench.bytes_algo(E, N, R, F) / 1e9 - 4.588) < 5e-4
     assert abs(bench.bytes_min(E, N, R, F) / 1e6 - 248.7) < 0.05
     assert abs(bench.bytes_algo(100_000_000, 10_000_000, 1000, 64) / 1e9 - 29.4) < 0.05
+
+
+def test_relation_cache_is_per_context_exact_and_dropped_by_training():
+    """task.cache_relation_representations on the CPU (the oracle plays every operator): predictions with the cached
+    tables equal per-batch recomputation exactly, in each of two graph contexts with different relation vocabularies;
+    train() and load_state_dict() drop the tables."""
+    from oracle_ops import oracle_rspmm
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    ta, na, ra = synthetic_triples((120, 700, 5), 1)
+    tb, nb, rb = synthetic_triples((80, 400, 3), 2)
+    torch.manual_seed(0)
+    task = build_ultra(ra, hidden_dims=(64, 64), rel_layers=2, num_negative=8)
+    task.add_context("a", Graph(_t(ta), num_node=na, num_relation=ra))
+    task.add_context("b", Graph(_t(tb), num_node=nb, num_relation=rb))
+    task.eval()
+    with torch.no_grad(), oracle_rspmm(0):
+        plain = {"a": task.use("a").predict(_t(ta[:5])), "b": task.use("b").predict(_t(tb[:5]))}
+        task.use("a").cache_relation_representations(batch_size=2)
+        task.use("b").cache_relation_representations(batch_size=4)
+        assert set(task._relation_cache) == {"a", "b"}
+        assert task._relation_cache["a"][0].shape[0] == ra and task._relation_cache["b"][0].shape[0] == rb
+        assert torch.equal(task.use("a").predict(_t(ta[:5])), plain["a"])
+        assert torch.equal(task.use("b").predict(_t(tb[:5])), plain["b"])
+    task.train()
+    assert not task._relation_cache
+    task.eval()
+    with torch.no_grad(), oracle_rspmm(0):
+        task.use("a").cache_relation_representations()
+    task.load_state_dict(task.state_dict())
+    assert not task._relation_cache
+    with pytest.raises(RuntimeError):
+        task.train().cache_relation_representations()

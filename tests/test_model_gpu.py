@@ -128,6 +128,38 @@ def test_evaluate_with_graph_replay_equals_eager_evaluation():
     assert all(torch.equal(metric_g[k], metric_e[k]) for k in metric_e)
 
 
+def test_cached_relation_representations_give_the_same_scores_and_ranks():
+    """task.cache_relation_representations (every relation's table computed once per evaluation run instead of once per
+    batch): scores of `predict`, eager and replayed as a hipGraph, and the ranks of engine.evaluate are IDENTICAL to the
+    per-batch computation -- a query's columns never see its batch mates.  train() drops the cache."""
+    from ultra_torchdrug_amd import engine
+    from ultra_torchdrug_amd.engine import GraphedPredict
+    task, triples = _build("S-tiny")
+    dev = torch.device("cuda:0")
+    task.to(dev).eval()
+    batches = [torch.from_numpy(triples[i:i + 8]).to(dev) for i in (0, 8, 16)]
+    with torch.no_grad():
+        plain = [task.predict(b).clone() for b in batches]
+        task.cache_relation_representations(batch_size=4)       # 6 relations: a full pass and a ragged one
+        assert task._relation_cache
+        cached = [task.predict(b).clone() for b in batches]
+    for a, b in zip(plain, cached):
+        assert torch.equal(a, b)
+    graphed = GraphedPredict(task, batches[0])
+    for b, want in zip(batches, plain):
+        got = graphed(b)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    task.train()
+    assert not task._relation_cache
+    task.eval()
+    queries = torch.from_numpy(triples[:37])
+    _, with_cache = engine.evaluate(task, queries, batch_size=8, cache_relations=True)
+    assert not task._relation_cache                             # dropped at the end of the run
+    _, without = engine.evaluate(task, queries, batch_size=8, cache_relations=False)
+    assert torch.equal(with_cache, without)
+
+
 def test_inductive_zero_shot_inference_matches_oracle_path():
     """configs[0] of BASELINE.json in miniature: weights meet a graph with OTHER entities at test time (inductive
     split, ultra/task.py:525-634); HIP path vs the same model with the CPU oracle as operator."""

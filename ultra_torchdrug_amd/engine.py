@@ -158,21 +158,33 @@ class GraphedTrainStep:
 
 
 @torch.no_grad()
-def evaluate(task, triples, batch_size=16, graphed=None):
+def evaluate(task, triples, batch_size=16, graphed=None, cache_relations=None):
     """Filtered ranking of ``triples`` ((n, 3) rows of (h, t, r)) sharded over ranks; every rank returns the
     metrics of the WHOLE set.  Only int64 ranks cross ranks.  ``graphed`` (default: on a GPU, when the shard holds at
-    least two full batches): ``predict`` is captured once and replayed as a hipGraph for every full batch."""
+    least two full batches): ``predict`` is captured once and replayed as a hipGraph for every full batch.
+    ``cache_relations`` (default: in eval mode, when the shard has more batches than the relation vocabulary needs
+    passes): the relation representations of all R relations are computed once for the run
+    (``task.cache_relation_representations``) instead of once per batch -- same bits, the relation stack leaves the
+    per-batch path.  The cache is dropped before returning."""
     device = task.device
     mine = shard_indices(len(triples))
     local = triples[mine].to(device)
     if graphed is None:
         graphed = device.type == "cuda" and len(local) >= 2 * batch_size and not task.training
-    replay = GraphedPredict(task, local[:batch_size]) if graphed and len(local) >= batch_size else None
-    ranks = []
-    for i in range(0, len(local), batch_size):
-        batch = local[i:i + batch_size]
-        pred = replay(batch) if replay is not None and len(batch) == batch_size else None
-        ranks.append(task.rank_batch(batch, pred=pred))
+    if cache_relations is None:
+        cache_relations = not task.training and len(local) > task.num_relation
+    if cache_relations:
+        task.cache_relation_representations(batch_size)
+    try:
+        replay = GraphedPredict(task, local[:batch_size]) if graphed and len(local) >= batch_size else None
+        ranks = []
+        for i in range(0, len(local), batch_size):
+            batch = local[i:i + batch_size]
+            pred = replay(batch) if replay is not None and len(batch) == batch_size else None
+            ranks.append(task.rank_batch(batch, pred=pred))
+    finally:
+        if cache_relations:
+            task.clear_relation_cache()
     ranks = torch.cat(ranks) if ranks else torch.zeros(0, 2, dtype=torch.long, device=device)
     ranking = gather_variable(ranks)
     return task.evaluate(ranking), ranking

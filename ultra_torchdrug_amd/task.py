@@ -41,6 +41,7 @@ class KnowledgeGraphCompletion(nn.Module):
                  fact_ratio=None, sample_weight=False, metric_per_rel=False, full_batch_eval=False):
         super().__init__()
         assert strict_negative                                   # task.py:27
+        self._relation_cache = {}                                # graph context -> per relation model (R, 2R, 64) tables
         self.model = model
         self.rel_models = rel_models
         self.criterion = {criterion: 1} if isinstance(criterion, str) else dict(criterion)
@@ -235,8 +236,47 @@ class KnowledgeGraphCompletion(nn.Module):
 
     # ------------------------------------------------------------------ predict (task.py:228-277)
     def relation_representations(self, pos_r_index, all_loss=None, metric=None):
+        cache = self._relation_cache.get(self.split) if self._relation_cache else None
+        if cache is not None and all_loss is None and not self.training and not torch.is_grad_enabled():
+            return [table[pos_r_index] for table in cache]
         return [rel_model(rel_graph, None, pos_r_index, all_loss=all_loss, metric=metric)["node_feature"]
                 for rel_model, rel_graph in zip(self.rel_models, self.rel_graphs)]
+
+    @torch.no_grad()
+    def cache_relation_representations(self, batch_size=16):
+        """Inference only, opt-in.  The relation representations of a query depend on the relation graph, the weights
+        and the query's relation alone (ultra/rel_model.py:351-378: the boundary is one row of ones at ``r``), and every
+        query of a batch is computed in its own columns -- so the ``(2R, 64)`` table of each of the R relations is
+        computed ONCE here (R / batch_size passes of the relation stack) and ``predict`` then picks the rows of its
+        batch: the same bits as recomputing them per batch, as the reference does (task.py:238-240), without a sixth
+        of an evaluation batch's time on an FB15k237-sized vocabulary.  Dropped by ``train()``,
+        ``load_state_dict()`` and :meth:`clear_relation_cache`; one table per graph context."""
+        if self.training:
+            raise RuntimeError("cache_relation_representations: evaluation only (call eval() first)")
+        self._relation_cache.pop(self.split, None)
+        device = next(self.parameters()).device
+        n_rel = self.fact_graph.num_relation
+        parts = [self.relation_representations(torch.arange(i, min(i + batch_size, n_rel), device=device))
+                 for i in range(0, n_rel, batch_size)]
+        self._relation_cache[self.split] = [torch.cat([p[m] for p in parts]) for m in range(len(self.rel_models))]
+        return self
+
+    def clear_relation_cache(self):
+        self._relation_cache.clear()
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            self._relation_cache.clear()          # the weights are about to change
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._relation_cache.clear()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):                       # .to(device) / .float() / ...
+        self._relation_cache.clear()
+        return super()._apply(fn, *args, **kwargs)
 
     def _select(self, batch):
         """Multi-graph pre-training batches are ``(triples, graph_id)`` (task.py:722-731): switch to that graph."""
