@@ -1485,7 +1485,16 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
         if (cs != hipStreamCaptureStatusNone) ev_start = ev_stop = nullptr;
     }
     if (ev_start != nullptr) HIP_TRY(hipEventRecord(ev_start, s));
-    HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_dst * (size_t)F * sizeof(float), s));
+    // zero fill as a kernel of this library, not hipMemsetAsync: under hipGraph capture a memset becomes a memset NODE,
+    // and a replayed graph was observed to run it out of order with the kernel nodes around it (first-layer outputs of
+    // every batch but the captured one were wrong when few kernels preceded it in the graph).  `out` is 16-byte aligned
+    // and F % 64 == 0 (checked above).
+    {
+        const long long n4 = (long long)n_dst * F / 4;
+        const unsigned blocks = (unsigned)((n4 + 256 * 8 - 1) / (256 * 8) < 4096 ? (n4 + 256 * 8 - 1) / (256 * 8) : 4096);
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<qf4 *>(out), n4);
+        HIP_TRY(hipGetLastError());
+    }
     FrontierParams p;
     p.src_ptr = src_ptr;
     p.dst = by_src->node_a;
