@@ -468,3 +468,28 @@ def test_relation_cache_is_per_context_exact_and_dropped_by_training():
     assert not task._relation_cache
     with pytest.raises(RuntimeError):
         task.train().cache_relation_representations()
+
+
+def test_unique_query_evaluation_equals_the_triple_loop_on_the_cpu_path():
+    """engine.evaluate(unique_queries=True) with the oracle playing every operator: the ranks of the batch-of-triples
+    loop, on triples that share heads, tails and whole rows; a ragged last chunk of queries."""
+    from oracle_ops import oracle_rspmm
+    from ultra_torchdrug_amd import engine
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    tr, n, r = synthetic_triples((90, 500, 4), 5)
+    torch.manual_seed(0)
+    task = build_ultra(r, hidden_dims=(64, 64), rel_layers=2, num_negative=8, full_batch_eval=True)
+    task.preprocess(Graph(_t(tr), num_node=n, num_relation=r)).eval()
+    base = _t(tr[:12])
+    again = base[:6].clone()
+    again[:, 1] = base[6:12, 1]                                   # same (h, r), other tails
+    queries = torch.cat([base, again, base[:3]])                  # 21 triples -> at most 42 queries, chunks of 8
+    with torch.no_grad(), oracle_rspmm(0):
+        _, want = engine.evaluate(task, queries, batch_size=4, graphed=False, cache_relations=False, unique_queries=False)
+        _, got = engine.evaluate(task, queries, batch_size=4, graphed=False, cache_relations=True, unique_queries=True)
+        direct = engine._ranks_of_unique_queries(task, queries, 4, False)     # (not the fallback to the triple loop)
+    assert got.shape == (21, 2) and torch.equal(got, want)
+    assert direct is not None and torch.equal(direct, want)
+    assert torch.equal(got[:3], got[18:])

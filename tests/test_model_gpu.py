@@ -160,6 +160,27 @@ def test_cached_relation_representations_give_the_same_scores_and_ranks():
     assert torch.equal(with_cache, without)
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_evaluation_over_unique_queries_gives_the_ranks_of_the_triple_loop(graphed):
+    """engine.evaluate(unique_queries=True): every distinct (anchor, relation) query of the test set is scored once and
+    every triple ranks its own target in those scores -- the (n, 2) ranks and the metrics of the batch-of-triples loop
+    (the reference's, task.py:228-277 + :307-351), on a test set built to share heads, tails and whole triples, with a
+    ragged last chunk of queries."""
+    from ultra_torchdrug_amd import engine
+    task, triples = _build("S-tiny")
+    dev = torch.device("cuda:0")
+    task.to(dev).eval()
+    base = torch.from_numpy(triples[:60])
+    shared_head = base[:20].clone(); shared_head[:, 1] = base[20:40, 1]          # same (h, r), other tails
+    shared_tail = base[:20].clone(); shared_tail[:, 0] = base[40:60, 0]          # same (t, r), other heads
+    queries = torch.cat([base, shared_head, shared_tail, base[:7]])             # 107 triples, 7 of them twice
+    m_u, r_u = engine.evaluate(task, queries, batch_size=8, graphed=graphed, unique_queries=True)
+    m_t, r_t = engine.evaluate(task, queries, batch_size=8, graphed=graphed, unique_queries=False)
+    assert r_u.shape == (107, 2) and torch.equal(r_u, r_t)
+    assert all(torch.equal(m_u[k], m_t[k]) for k in m_t)
+    assert torch.equal(r_u[:7], r_u[100:])                                       # duplicated triples: same ranks
+
+
 def test_inductive_zero_shot_inference_matches_oracle_path():
     """configs[0] of BASELINE.json in miniature: weights meet a graph with OTHER entities at test time (inductive
     split, ultra/task.py:525-634); HIP path vs the same model with the CPU oracle as operator."""

@@ -157,15 +157,102 @@ class GraphedTrainStep:
         return self.static_loss.detach(), reduce_metrics(self.static_metric)
 
 
+class GraphedScores:
+    """Scores ``(Q, N)`` of Q tail-form queries ``(anchor, relation in [0, 2R), ?)`` -- ``score_all_entities`` of the
+    entity model on the relation representations of ``base_relation`` -- captured once and replayed as a hipGraph
+    (the query-level counterpart of :class:`GraphedPredict`, which takes triples)."""
+
+    def __init__(self, task, anchor, relation, base_relation, graphed=True, warmup=3):
+        self.task = task
+        self.static = [anchor.clone(), relation.clone(), base_relation.clone()]
+        self.graph, self.static_pred = None, None
+        if not graphed:
+            return
+        model = task.model
+        model.check_indices = False
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):
+                    self._scores(*self.static)
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
+                self.static_pred = self._scores(*self.static)
+        finally:
+            model.check_indices = True
+
+    def _scores(self, anchor, relation, base_relation):
+        rel_inputs = self.task.relation_representations(base_relation)
+        return self.task.model.score_all_entities(self.task.fact_graph, rel_inputs, anchor, relation)
+
+    def __call__(self, anchor, relation, base_relation):
+        """The returned tensor is overwritten by the next call."""
+        if self.graph is None or anchor.shape != self.static[0].shape:
+            with torch.no_grad():
+                return self._scores(anchor, relation, base_relation)
+        for dst, src in zip(self.static, (anchor, relation, base_relation)):
+            dst.copy_(src)
+        self.graph.replay()
+        return self.static_pred
+
+
+def _ranks_of_unique_queries(task, local, batch_size, graphed):
+    """``(n, 2)`` filtered ranks of the triples ``local`` with every DISTINCT query scored once.  A test set asks
+    ``(h, r, ?)`` and ``(?, r, t)`` for each triple; triples that share the head and the relation share the tail query
+    (and popular tails share head queries), and a query's scores do not depend on its batch mates, so the Bellman-Ford
+    runs over the distinct queries only, ``2 * batch_size`` at a time, and every triple ranks its own target in the
+    scores of its query.  ``None`` when the model has no fused all-entity score path (the caller keeps the triple loop)."""
+    from . import backend
+    ops = backend.get()
+    n = len(local)
+    h, t, r = local.t()
+    n_rel = task.num_relation
+    graph = task.graph
+    anchor, q_rel = torch.cat([h, t]), torch.cat([r, r + n_rel])                # tail form (model.py:76-83)
+    target, base = torch.cat([t, h]), torch.cat([r, r])
+    uniq, inverse = torch.unique(anchor * (2 * n_rel) + q_rel, return_inverse=True)
+    u_anchor, u_rel = uniq // (2 * n_rel), uniq % (2 * n_rel)
+    u_base = torch.where(u_rel >= n_rel, u_rel - n_rel, u_rel)
+    order = torch.argsort(inverse, stable=True)                                 # entries grouped by their query
+    first = torch.searchsorted(inverse[order], torch.arange(len(uniq) + 1, device=local.device))
+    chunk = 2 * batch_size
+    keys = (graph.completion_keys(0), graph.completion_keys(1)) if task.filtered_ranking else (None, None)
+    rank_rel = max(graph.num_relation, 1)
+    ranks = torch.empty(2 * n, dtype=torch.long, device=local.device)
+    scorer = None
+    bounds = first.tolist()
+    for c in range(0, len(uniq), chunk):
+        ids = torch.arange(c, c + chunk, device=local.device).clamp(max=len(uniq) - 1)       # the last chunk repeats its end
+        args = (u_anchor[ids], u_rel[ids], u_base[ids])
+        if scorer is None:
+            probe = GraphedScores(task, *args, graphed=False)
+            if probe(*args) is None:                     # no fused all-entity score path for this model
+                return None
+            scorer = GraphedScores(task, *args, graphed=bool(graphed) and len(uniq) >= 2 * chunk)
+        scores = scorer(*args)
+        entries = order[bounds[c]:bounds[min(c + chunk, len(uniq))]]
+        rows = scores[inverse[entries] - c]                                     # (k, N): each entry's query row
+        for side in (0, 1):                                                     # tails, heads: their own completion keys
+            pick = (entries < n) if side == 0 else (entries >= n)
+            e = entries[pick]
+            if len(e):
+                ranks[e] = ops.filtered_rank_keys(rows[pick], target[e], keys[side], anchor[e], base[e], rank_rel)
+    return torch.stack([ranks[:n], ranks[n:]], dim=1)
+
+
 @torch.no_grad()
-def evaluate(task, triples, batch_size=16, graphed=None, cache_relations=None):
+def evaluate(task, triples, batch_size=16, graphed=None, cache_relations=None, unique_queries=None):
     """Filtered ranking of ``triples`` ((n, 3) rows of (h, t, r)) sharded over ranks; every rank returns the
     metrics of the WHOLE set.  Only int64 ranks cross ranks.  ``graphed`` (default: on a GPU, when the shard holds at
     least two full batches): ``predict`` is captured once and replayed as a hipGraph for every full batch.
     ``cache_relations`` (default: in eval mode, when the shard has more batches than the relation vocabulary needs
     passes): the relation representations of all R relations are computed once for the run
     (``task.cache_relation_representations``) instead of once per batch -- same bits, the relation stack leaves the
-    per-batch path.  The cache is dropped before returning."""
+    per-batch path.  The cache is dropped before returning.  ``unique_queries`` (default: in eval mode on a GPU with
+    full-batch evaluation): every distinct query of the shard is scored once (:func:`_ranks_of_unique_queries`) --
+    same ranks, fewer Bellman-Ford passes on test sets whose triples share heads or tails."""
     device = task.device
     mine = shard_indices(len(triples))
     local = triples[mine].to(device)
@@ -175,17 +262,22 @@ def evaluate(task, triples, batch_size=16, graphed=None, cache_relations=None):
         cache_relations = not task.training and len(local) > task.num_relation
     if cache_relations:
         task.cache_relation_representations(batch_size)
+    if unique_queries is None:
+        unique_queries = (device.type == "cuda" and not task.training and task.full_batch_eval and task.fuse_sides
+                          and len(local) > 0)
     try:
-        replay = GraphedPredict(task, local[:batch_size]) if graphed and len(local) >= batch_size else None
-        ranks = []
-        for i in range(0, len(local), batch_size):
-            batch = local[i:i + batch_size]
-            pred = replay(batch) if replay is not None and len(batch) == batch_size else None
-            ranks.append(task.rank_batch(batch, pred=pred))
+        ranks = _ranks_of_unique_queries(task, local, batch_size, graphed) if unique_queries and len(local) else None
+        if ranks is None:
+            replay = GraphedPredict(task, local[:batch_size]) if graphed and len(local) >= batch_size else None
+            ranks = []
+            for i in range(0, len(local), batch_size):
+                batch = local[i:i + batch_size]
+                pred = replay(batch) if replay is not None and len(batch) == batch_size else None
+                ranks.append(task.rank_batch(batch, pred=pred))
+            ranks = torch.cat(ranks) if ranks else torch.zeros(0, 2, dtype=torch.long, device=device)
     finally:
         if cache_relations:
             task.clear_relation_cache()
-    ranks = torch.cat(ranks) if ranks else torch.zeros(0, 2, dtype=torch.long, device=device)
     ranking = gather_variable(ranks)
     return task.evaluate(ranking), ranking
 
