@@ -446,6 +446,24 @@ def main():
                 "hits@1": float((r <= 1).float().mean()), "hits@3": float((r <= 3).float().mean()),
                 "hits@10": float((r <= 10).float().mean())}
 
+    # ---------------- whole evaluation runs over the seeded test triples (engine.evaluate), three ways, same ranks ----
+    eval_runs = None
+    if rank == 0 and world == 1 and args.mrr_queries > 0:
+        from ultra_torchdrug_amd import engine
+        eval_runs = {"triples": int(len(test))}
+        checks = []
+        for name, kw in (("reference_loop", dict(cache_relations=False, unique_queries=False)),
+                         ("cached_relations", dict(cache_relations=True, unique_queries=False)),
+                         ("cached_relations_unique_queries", dict(cache_relations=True, unique_queries=True))):
+            engine.evaluate(task, test[:4 * B], batch_size=B, **kw)        # first-use costs (code object loads) stay outside
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            _, ranking = engine.evaluate(task, test, batch_size=B, **kw)
+            torch.cuda.synchronize()
+            eval_runs[name + "_ms"] = 1e3 * (time.perf_counter() - t_e)
+            checks.append(ranking)
+        eval_runs["ranks_identical"] = bool(all(torch.equal(checks[0], c) for c in checks[1:]))
+
     mrr = mrr_tuned = None
     metrics = metrics_tuned = None
     mrr_check = []
@@ -528,6 +546,7 @@ def main():
                 "value_entity_only_with_cached_relation_representations":
                     entity_edges_per_step / (cached_ms * 1e-3) if cached_ms else None,
                 "relation_cache_build_ms": cache_build_ms,
+                "evaluate_test_set": eval_runs,
                 "graph_replays_identical_to_eager": {"per_batch_relations": replay_same, "cached_relations": replay_same_cached},
                 "relation_cache_note": "opt-in (engine.evaluate default for long runs): the relation representations of a "
                                        "query depend on its relation only, so all R tables are computed once per "
