@@ -132,6 +132,17 @@ def cpu_baseline(graph_np, n_node, n_rel, F, budget_s=20.0):
                       % (len(times), csr.n_edges, F, F // 64, med)}
 
 
+def stress_traffic():
+    """HBM bytes per launch of the S-stress kernel from separate rocprofv3 --pmc passes of the same kernel and workload,
+    committed under profiles/ (not measured in this run)."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic_stress.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch"), "profiles/r02_traffic_stress.json (rocprofv3 --pmc passes, not this run)"
+    except OSError:
+        return None, None
+
+
 def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel=500):
     """Config 5 at size: S-stress -- uniform triples + inverse edges => E = 100 M, R = 1 000, 64d,
     B = 1.  The gathered matrix (2.56 GB) cannot live in any cache: the HBM roofline of the operator."""
@@ -170,7 +181,8 @@ def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel
     return {"bound": "hbm", "workload": "S-stress N=%d E=%d R=%d B=1 F=64 (input %.2f GB)" % (n_node, E, R, n_node * F * 4 / 1e9),
             "kernel": kernel, "launches_timed": n, "kernel_ms": ms, "algorithmic_bytes": algo,
             "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": stress_traffic()[0],
+            "traffic_source": stress_traffic()[1],
             "edges_per_s": E / (ms * 1e-3), "chunked_kernel_ms": ms_chunked, "plan_build_s": build_s}
 
 
