@@ -51,9 +51,14 @@ class _TallLinear(torch.autograd.Function):
                 g_p[:rows], x_p[:rows] = g, x
             else:
                 g_p, x_p = g, x
-            d_weight = torch.bmm(g_p.view(s, per, -1).transpose(1, 2), x_p.view(s, per, -1)).sum(0)
-        if ctx.needs_input_grad[2]:
-            d_bias = g.sum(0)
+            parts = torch.bmm(g_p.view(s, per, -1).transpose(1, 2), x_p.view(s, per, -1))          # (s, out, in)
+            # the sum over the slices as a (1, s) x (s, out * in) product: ATen's strided `sum(0)` of this shape is a
+            # multi-block reduction that zeroes its semaphores with a memset, and a memset NODE inside a captured
+            # training step is one more thing that could replay out of order (see ultra_rspmm_frontier_f32)
+            ones = torch.ones(1, s, dtype=parts.dtype, device=parts.device)
+            d_weight = (ones @ parts.view(s, -1)).view(parts.shape[1], parts.shape[2])
+        if ctx.needs_input_grad[2]:          # (a product for the same reason as above)
+            d_bias = (torch.ones(1, g.shape[0], dtype=g.dtype, device=g.device) @ g).view(-1)
         return d_input, d_weight, d_bias
 
 
