@@ -1,0 +1,57 @@
+"""Does a hipMemsetAsync captured into a hipGraph (a memset NODE) keep its place between the kernel nodes around it?
+
+Context: ultra_rspmm_frontier_f32 used hipMemsetAsync for its zero fill; inside a short captured graph (few kernels in
+front of it) replays on batches other than the captured one produced wrong first-layer outputs, and the fault went away
+with a fill KERNEL in its place.  This script tries the bare pattern: memset(out) -> kernel writes a few rows of out ->
+kernel reads out, captured once and replayed with other inputs, against eager execution.
+    python tools/debug/memset_node_repro.py
+"""
+import ctypes
+
+import torch
+
+
+def main():
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipMemsetAsync.restype = ctypes.c_int
+    dev = torch.device("cuda:0")
+    n, f = 300, 1024
+    static_idx = torch.randint(0, n, (16,), device=dev)
+    static_val = torch.randn(16, f, device=dev)
+
+    def body(idx, val, use_memset):
+        out = torch.empty(n, f, device=dev)
+        if use_memset:
+            rc = hip.hipMemsetAsync(out.data_ptr(), 0, out.numel() * 4, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+        else:
+            out.zero_()
+        out.index_copy_(0, idx, val)               # a kernel that writes a few rows
+        return out * 2.0 + 1.0                     # a kernel that reads everything
+
+    for use_memset in (True, False):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                body(static_idx, static_val, use_memset)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            res = body(static_idx, static_val, use_memset)
+        bad = 0
+        for trial in range(20):
+            idx = torch.randperm(n, device=dev)[:16]
+            val = torch.randn(16, f, device=dev)
+            static_idx.copy_(idx)
+            static_val.copy_(val)
+            g.replay()
+            torch.cuda.synchronize()
+            want = body(idx, val, False)
+            bad += int(not torch.equal(res, want))
+        print("zero fill by %s: %d of 20 replays differ from eager" % ("hipMemsetAsync (memset node)" if use_memset else "fill kernel", bad))
+
+
+if __name__ == "__main__":
+    main()

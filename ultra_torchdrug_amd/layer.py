@@ -54,7 +54,7 @@ class _TallLinear(torch.autograd.Function):
             parts = torch.bmm(g_p.view(s, per, -1).transpose(1, 2), x_p.view(s, per, -1))          # (s, out, in)
             # the sum over the slices as a (1, s) x (s, out * in) product: ATen's strided `sum(0)` of this shape is a
             # multi-block reduction that zeroes its semaphores with a memset, and a memset NODE inside a captured
-            # training step is one more thing that could replay out of order (see ultra_rspmm_frontier_f32)
+            # training step is one more node kind whose replay has misbehaved here (see ultra_rspmm_frontier_f32)
             ones = torch.ones(1, s, dtype=parts.dtype, device=parts.device)
             d_weight = (ones @ parts.view(s, -1)).view(parts.shape[1], parts.shape[2])
         if ctx.needs_input_grad[2]:          # (a product for the same reason as above)
