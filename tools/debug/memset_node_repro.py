@@ -2,8 +2,11 @@
 
 Context: ultra_rspmm_frontier_f32 used hipMemsetAsync for its zero fill; inside a short captured graph (few kernels in
 front of it) replays on batches other than the captured one produced wrong first-layer outputs, and the fault went away
-with a fill KERNEL in its place.  This script tries the bare pattern: memset(out) -> kernel writes a few rows of out ->
-kernel reads out, captured once and replayed with other inputs, against eager execution.
+with a fill KERNEL in its place.  The pattern: a temporary is written, read and freed; `out` is allocated (inside the
+graph's memory pool it takes over the temporary's block); memset(out) -> a kernel writes a few rows of out -> a kernel
+reads out; captured once, replayed with other inputs, compared with eager execution.  Observed on MI355X / ROCm 7.2
+with the HIP runtime of PyTorch 2.10+rocm7.0: 19 of 20 replays differ with hipMemsetAsync, 0 of 20 with a fill kernel
+(and 0 of 20 with hipMemsetAsync when the temporary is left out: no block reuse, no hazard).
     python tools/debug/memset_node_repro.py
 """
 import ctypes
@@ -21,6 +24,11 @@ def main():
     static_val = torch.randn(16, f, device=dev)
 
     def body(idx, val, use_memset):
+        # a temporary that is written, read and freed BEFORE `out` is allocated: inside the graph's memory pool `out`
+        # takes over its block, so a fill that ran early (or not at all) would show
+        tmp = val.repeat(n // 16 + 1, 1)[:n] * 3.0
+        carry = tmp.sum()
+        del tmp
         out = torch.empty(n, f, device=dev)
         if use_memset:
             rc = hip.hipMemsetAsync(out.data_ptr(), 0, out.numel() * 4, torch.cuda.current_stream().cuda_stream)
@@ -28,7 +36,7 @@ def main():
         else:
             out.zero_()
         out.index_copy_(0, idx, val)               # a kernel that writes a few rows
-        return out * 2.0 + 1.0                     # a kernel that reads everything
+        return out * 2.0 + 1.0 + carry * 0.0        # a kernel that reads everything
 
     for use_memset in (True, False):
         side = torch.cuda.Stream()

@@ -1488,8 +1488,10 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
     // zero fill as a kernel of this library, not hipMemsetAsync: under hipGraph capture a memset becomes a memset NODE,
     // and replays of a short graph (few kernels in front of it) did not reproduce the eager result -- first-layer
     // outputs right on the captured batch, wrong on every other one -- while the same graph with a fill kernel does
-    // (tests/test_model_gpu.py::test_cached_relation_representations_...; the bare pattern replays correctly, the
-    // trigger is not understood: tools/debug/memset_node_repro.py).  `out` is 16-byte aligned and F % 64 == 0.
+    // (tests/test_model_gpu.py::test_cached_relation_representations_...).  Minimal pattern, tools/debug/
+    // memset_node_repro.py: if the filled buffer has taken over, in the graph's memory pool, the block of a temporary
+    // that earlier kernel nodes wrote and read, the memset node is not ordered after them (19 of 20 replays wrong; 0 of
+    // 20 with a fill kernel).  `out` is 16-byte aligned and F % 64 == 0.
     {
         const long long n4 = (long long)n_dst * F / 4;
         const unsigned blocks = (unsigned)((n4 + 256 * 8 - 1) / (256 * 8) < 4096 ? (n4 + 256 * 8 - 1) / (256 * 8) : 4096);
