@@ -493,3 +493,18 @@ def test_unique_query_evaluation_equals_the_triple_loop_on_the_cpu_path():
     assert got.shape == (21, 2) and torch.equal(got, want)
     assert direct is not None and torch.equal(direct, want)
     assert torch.equal(got[:3], got[18:])
+
+
+@pytest.mark.parametrize("shape", [(7, 3, 64), (513, 2, 64), (300, 16, 64)])
+def test_feature_statistics_equal_the_reference_formulas(shape):
+    """TransferNBFNet._feature_statistics (one chunked pass over `hidden`, the query part added analytically) against
+    the reference's three passes over the materialised feature tensor (ultra/model.py:178-180: norm, mean, std)."""
+    from ultra_torchdrug_amd.model import TransferNBFNet
+    gen = torch.Generator().manual_seed(shape[0])
+    hidden = torch.randn(*shape, generator=gen).relu() + 0.1
+    query = torch.randn(shape[1], 64, generator=gen)
+    feature = torch.cat([hidden, query.expand(shape[0], -1, -1)], dim=-1).transpose(0, 1).double()
+    metric = {}
+    TransferNBFNet._feature_statistics(metric, hidden, query)
+    for key, want in (("output_norm", feature.norm()), ("output_mean", feature.mean()), ("output_std", feature.std())):
+        assert abs(metric[key].item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-7, key

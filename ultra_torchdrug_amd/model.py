@@ -267,18 +267,33 @@ class TransferNBFNet(nn.Module):
     @staticmethod
     def _feature_statistics(metric, hidden, query):
         """``output_norm / output_mean / output_std`` of model.py:178-180 for ``feature = cat[hidden, query]`` (query
-        repeated for every node) from ONE pass over ``hidden``: sums and sums of squares of the two parts add up."""
+        repeated for every node) from ONE pass over ``hidden``: sums and sums of squares of the two parts add up.
+        The pass is two chunked row reductions (16 K elements per output, then a few thousand partials): ATen's
+        ``var_mean`` / full ``sum`` of a tensor this size are multi-block reductions that zero their semaphores with a
+        memset, and a memset node does not replay reliably inside a captured training step (frontier
+        paragraph)."""
         n_node = hidden.shape[0]
-        var_h, mean_h = torch.var_mean(hidden.float())
-        n_h = hidden.numel()
-        sum_h, sq_h = mean_h * n_h, var_h * (n_h - 1) + mean_h * mean_h * n_h
-        sum_q, sq_q = query.sum() * n_node, (query * query).sum() * n_node
+        flat = hidden.float().reshape(-1)
+        n_h = flat.numel()
+        chunk = 16384
+        main = n_h - n_h % chunk
+        sum_h = flat.new_zeros((), dtype=torch.float64)
+        sq_h = flat.new_zeros((), dtype=torch.float64)
+        if main:
+            parts = flat[:main].view(-1, chunk)
+            sum_h = sum_h + parts.sum(1).double().sum()
+            sq_h = sq_h + (torch.linalg.vector_norm(parts, dim=1).double() ** 2).sum()
+        if main != n_h:
+            tail = flat[main:].double()
+            sum_h, sq_h = sum_h + tail.sum(), sq_h + (tail * tail).sum()
+        q = query.double()
+        sum_q, sq_q = q.sum() * n_node, (q * q).sum() * n_node
         n = n_h + query.numel() * n_node
         mean = (sum_h + sum_q) / n
         sq = sq_h + sq_q
-        metric["output_norm"] = sq.sqrt()
-        metric["output_mean"] = mean
-        metric["output_std"] = ((sq - mean * mean * n) / (n - 1)).clamp(min=0).sqrt()
+        metric["output_norm"] = sq.sqrt().float()
+        metric["output_mean"] = mean.float()
+        metric["output_std"] = ((sq - mean * mean * n) / (n - 1)).clamp(min=0).sqrt().float()
 
     def _fused_score_ok(self, graph, t_index, metric):
         """The fused score head covers the shipped head (64-d hidden + 64-d query -> 128 -> 128 -> 1, relu),
