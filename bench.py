@@ -359,8 +359,10 @@ def main():
         gen = torch.Generator(device=dev).manual_seed(DEFAULT_SEED)
         xk = torch.randn(n_node, Fk, device=dev, generator=gen)
         rk = torch.randn(R2, Fk, device=dev, generator=gen)
-        bk = (torch.randint(0, n_node, (Fk // 64,), device=dev, generator=gen).to(torch.int32),
-              torch.randn(Fk // 64, 64, device=dev, generator=gen))            # the layer's sparse boundary
+        # the layer's sparse boundary: the heads and tails of a REAL batch (Zipf hubs: a uniformly drawn boundary would
+        # flatter the first-layer frontier kernel by an order of magnitude)
+        bk = (torch.cat([shard[:B, 0], shard[:B, 1]])[:Fk // 64].to(torch.int32).contiguous(),
+              torch.randn(Fk // 64, 64, device=dev, generator=gen))
         if graphed is not None:
             for _ in range(4):
                 real_forward(und.relcsr, rk, xk, "add", "mul", None, bk)
