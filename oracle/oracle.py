@@ -47,6 +47,31 @@ def lib():
     return _lib
 
 
+def native_forward_fn(threads=None):
+    """For ``bench.py``'s ``cpu_baseline`` leg only: the SAME source rebuilt ``-O3 -march=native`` (still
+    ``-ffp-contract=off``) on the machine that times it, in a temporary directory -- the committed Makefile's build must
+    run on any x86-64 host the snapshot travels to, a ``-march=native`` object need not.  Returns a function with the
+    signature of :func:`rspmm_forward`."""
+    import tempfile
+    out_dir = tempfile.mkdtemp(prefix="rspmm_oracle_native_")
+    so = os.path.join(out_dir, "librspmm_oracle_native.so")
+    subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off",
+                           "-fno-fast-math", "-fopenmp", "-shared", "-o", so, os.path.join(_HERE, "rspmm_oracle.c"), "-lm"])
+    native = ctypes.CDLL(so)
+    native.oracle_rspmm_forward.restype = ctypes.c_int
+
+    def forward(csr, relation, x, sum="add", mul="mul", piece=0):
+        F = x.shape[1]
+        out = np.empty((csr.n_rows, F), dtype=np.float32)
+        rc = native.oracle_rspmm_forward(_p(csr.row_ptr), _p(csr.col), _p(csr.rel), _p(csr.w), _p(relation), _p(x), _p(out),
+                                         _i64(csr.n_rows), _i64(csr.n_edges), _i64(csr.n_rel), _i64(F), SUM_OPS[sum],
+                                         MUL_OPS[mul], _i64(piece))
+        if rc:
+            raise RuntimeError("oracle_rspmm_forward (native build) failed: %d" % rc)
+        return out
+    return forward
+
+
 def _p(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(0)
 

@@ -110,6 +110,51 @@ def test_first_layer_uses_the_frontier_and_predict_is_unchanged():
     assert torch.equal(with_frontier, without)
 
 
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_frontier_non_finite_relation_table_takes_the_full_kernel(bad):
+    """``inf * 0 = NaN``: with a non-finite relation entry the full kernel writes NaN at EVERY destination of an edge of that
+    relation (its zero source rows included), the frontier kernel only along the boundary nodes' out-edges.  The layer
+    tests the table on eager calls and takes the full kernel then, so the first layer keeps the reference's result;
+    ``functional.rspmm_frontier`` itself documents finiteness as its precondition."""
+    from ultra_torchdrug_amd import RelCSR, functional as UF, layer
+    from ultra_torchdrug_amd.graph import Graph
+    dev = _dev()
+    n, r, B = 400, 6, 4
+    g = random_graph(seed=5, n_node=n, n_edge=5000, n_rel=r)
+    graph = Graph(torch.stack([_t(g["src"]), _t(g["dst"]), _t(g["rel"])], dim=1), num_node=n, num_relation=r)
+    rng = np.random.default_rng(3)
+    conv = layer.GeneralizedRelationalConvNBFMod(64, 64, r, 64, message_func="distmult", aggregate_func="sum",
+                                                 layer_norm=True, project=False).to(dev).eval()
+    table = torch.from_numpy(rng.standard_normal((B, r, 64)).astype(np.float32)).to(dev)
+    table[1, 2, 5] = bad                                                      # query 1, relation 2, column 5
+    conv.relation = table
+    node = torch.tensor([3, 9, 27, 81], dtype=torch.int32, device=dev)
+    value = torch.from_numpy(rng.standard_normal((B, 64)).astype(np.float32)).to(dev)
+    boundary = torch.zeros(n, B, 64, device=dev)
+    boundary[node.long(), torch.arange(B, device=dev)] = value
+    graph.query, graph.boundary, graph.boundary_sparse = value, boundary, (node, value)
+    relation_input = table.transpose(0, 1).flatten(1).contiguous()
+    want = UF.rspmm_forward(graph.relcsr, relation_input, boundary.flatten(1), "add", "mul", boundary=(node, value))
+    assert torch.isnan(want).any()
+    calls = []
+    real = UF.rspmm_frontier
+    UF.rspmm_frontier = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            got = conv.message_and_aggregate(graph, boundary, input_is_boundary=True)
+            table[1, 2, 5] = 0.25                                             # finite again: the shortcut is back
+            conv.message_and_aggregate(graph, boundary, input_is_boundary=True)
+    finally:
+        UF.rspmm_frontier = real
+    assert len(calls) == 1, "the non-finite table must not go through the frontier kernel"
+    assert torch.equal(torch.isnan(got.flatten(1)), torch.isnan(want))
+    assert torch.equal(torch.nan_to_num(got.flatten(1), nan=0.0), torch.nan_to_num(want, nan=0.0))
+    # what the guard protects against: the bare kernel reaches fewer rows
+    table[1, 2, 5] = bad
+    bare = UF.rspmm_frontier(graph.relcsr, table.transpose(0, 1).flatten(1).contiguous(), (node, value))
+    assert int(torch.isnan(bare).any(1).sum()) < int(torch.isnan(want).any(1).sum())
+
+
 # ------------------------------------------------------------------------------------------------ sampler
 def _kg(n=700, triples=6000, r=9, seed=4):
     from ultra_torchdrug_amd.data import synthetic_triples

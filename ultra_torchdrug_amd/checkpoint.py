@@ -30,17 +30,34 @@ class _Placeholder:
         pass
 
 
+_STORAGES = ("FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage", "ShortStorage",
+             "CharStorage", "ByteStorage", "BoolStorage", "ComplexFloatStorage", "ComplexDoubleStorage")
+_DTYPES = ("float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool", "complex64",
+           "complex128")
+# every global a tensors-only checkpoint (state dict + optimizer state) can refer to -- (module, name) pairs, nothing
+# resolved by package root: ``torch.*`` / ``numpy.*`` / ``builtins.*`` as roots also hold callables that run commands
+# (``torch.utils.collect_env.run``, ``numpy.testing._private.utils.runstring``, ``builtins.breakpoint`` ...)
+_ALLOWED_GLOBALS = frozenset(
+    [("collections", "OrderedDict"), ("collections", "defaultdict"),
+     ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+     ("torch", "Size"), ("torch", "device"), ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+     ("numpy", "ndarray"), ("numpy", "dtype"),
+     ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+     ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+     ("_codecs", "encode")]
+    + [("torch", name) for name in _STORAGES + _DTYPES]
+    + [("builtins", name) for name in ("set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "str", "bytes",
+                                       "bytearray", "complex", "slice", "range")])
+
+
 class _TensorsOnlyUnpickler(pickle.Unpickler):
-    """Resolves torch / numpy / builtin container globals only; every ``torchdrug.*`` global becomes a placeholder
+    """Resolves exactly the globals of ``_ALLOWED_GLOBALS``; every ``torchdrug.*`` global becomes an inert placeholder
     and anything else is refused -- a checkpoint is data, not code."""
-    _ALLOWED_ROOTS = ("torch", "numpy", "collections", "builtins", "_codecs")
 
     def find_class(self, module, name):
-        root = module.split(".")[0]
-        if root == "torchdrug":
+        if module.split(".")[0] == "torchdrug":
             return _Placeholder
-        if root not in self._ALLOWED_ROOTS or (root == "builtins" and name in ("eval", "exec", "compile", "open",
-                                                                               "__import__", "getattr", "setattr")):
+        if (module, name) not in _ALLOWED_GLOBALS:
             raise pickle.UnpicklingError("checkpoint refers to %s.%s, which a tensors-only checkpoint never needs"
                                          % (module, name))
         return super().find_class(module, name)
@@ -54,15 +71,20 @@ class _tensors_only_pickle:
 
 
 def read_checkpoint(path, map_location=None):
-    """``torch.load`` of a reference checkpoint without executing what it pickles: first as tensors only
-    (``weights_only=True``: what ``util.clean_save`` writes, ``ultra/util.py:278-325``); a file that still carries
-    torchdrug graph objects (``util.py:241-247`` drops them AFTER unpickling, which needs torchdrug installed) is
-    re-read with an unpickler that maps ``torchdrug.*`` classes to placeholders and refuses every other foreign
-    global.  Only load checkpoints from a source you trust either way."""
+    """``torch.load`` of a reference checkpoint as DATA.  First ``weights_only=True`` (what ``util.clean_save`` writes,
+    ``ultra/util.py:278-325``).  A file that still carries torchdrug graph objects (``util.py:241-247`` drops them
+    AFTER unpickling, which needs torchdrug installed) makes that loader refuse the ``torchdrug.*`` global; such a file
+    -- and only an ``UnpicklingError``, with a warning -- is re-read with an unpickler that resolves an explicit list of
+    ``(module, name)`` globals (tensor / storage rebuilders, ``OrderedDict``, numpy array rebuilders, plain builtin
+    containers), maps ``torchdrug.*`` classes to inert placeholders and refuses everything else.  Neither reader can be
+    made to call a function the file names."""
     path = os.path.expanduser(path)
     try:
         return torch.load(path, map_location=map_location, weights_only=True)
-    except (pickle.UnpicklingError, RuntimeError, AttributeError, ModuleNotFoundError):
+    except pickle.UnpicklingError:
+        import warnings
+        warnings.warn("%s is not a tensors-only file for torch.load(weights_only=True); re-reading it with the "
+                      "allow-listed unpickler (torchdrug objects become placeholders, other globals are refused)" % path)
         return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_tensors_only_pickle)
 
 

@@ -8,6 +8,12 @@
 // kernels live in libultra_rspmm.so, which this library links.  Built with hipcc against the torch headers
 // (csrc/Makefile, target torch); nothing here is generated or translated.
 //
+// CPU dispatch key (BASELINE config 1 runs with `--gpus null`, /root/reference/README.md:79,90): build_relcsr, rspmm_fwd and
+// rspmm_bwd also have host kernels, written here (at::parallel_for; per output element ONE sequential accumulation over
+// the row's sorted edges, `y = w * (rel (*|+) x)` rounded before `acc (+|min|max) y` -- this file is compiled with
+// -ffp-contract=off).  They are product code: nothing under oracle/ is included or linked; the tests hold them
+// bit-equal to the oracle's sequential order.
+//
 // Operators:
 //   ultra_mi::build_relcsr(edge_list, edge_weight?, num_node, num_relation) -> Tensor[]
 //       coalesced CSR over destination nodes of torchdrug's (node_in, node_out, relation) edge list:
@@ -18,14 +24,16 @@
 //   plan-based forms used by ultra_torchdrug_amd.functional (the plan = the bytes of one `ultra_segments` struct in a
 //   CPU uint8 tensor; the device arrays it points to are owned by the Python RelCSR object):
 //   ultra_mi::rspmm_plan_fwd(plan, relation, input, add_rows?, boundary_node?, boundary_value?, n_src, sum_op, mul_op) -> Tensor
-//   ultra_mi::rspmm_plan_bwd(by_src?, by_rel?, relation, input, output?, output_grad, d_input_add?, n_src, n_dst, sum_op, mul_op)
-//       -> (d_input, d_relation)
+//   ultra_mi::rspmm_plan_bwd(by_src?, by_rel?, relation, input, output?, output_grad, d_input(a!)?, accumulate, n_src, n_dst,
+//       sum_op, mul_op) -> d_relation          (d_input is written -- or accumulated into -- in place)
 #include <ATen/ATen.h>
+#include <ATen/Parallel.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/autograd.h>
 #include <torch/library.h>
 
+#include <cfloat>
 #include <cstring>
 #include <tuple>
 #include <vector>
@@ -319,46 +327,272 @@ Tensor rspmm_plan_fwd(const Tensor &plan, const Tensor &relation, const Tensor &
     return out;
 }
 
-std::tuple<Tensor, Tensor> rspmm_plan_bwd(const optional<Tensor> &by_src, const optional<Tensor> &by_rel,
-                                          const Tensor &relation, const Tensor &input, const optional<Tensor> &output,
-                                          const Tensor &output_grad, const optional<Tensor> &d_input_add, int64_t n_src,
-                                          int64_t n_dst, int64_t sum_op, int64_t mul_op) {
+// d_input is an OUT argument (schema: Tensor(a!)?): the caller allocates it -- or hands over the gradient the same rows
+// already hold from the layer's dense epilogue together with accumulate = true, and the kernels add the edge gradient
+// INTO it (they read every element before they write it: no separate add pass, no extra (N, F) tensor).  Returns
+// d_relation only, so no input is ever returned as an un-annotated output (dispatcher contract).
+Tensor rspmm_plan_bwd(const optional<Tensor> &by_src, const optional<Tensor> &by_rel, const Tensor &relation,
+                      const Tensor &input, const optional<Tensor> &output, const Tensor &output_grad,
+                      const optional<Tensor> &d_input_out, bool accumulate, int64_t n_src, int64_t n_dst, int64_t sum_op,
+                      int64_t mul_op) {
     const ultra_segments *s_src = plan_of(by_src, "by_src"), *s_rel = plan_of(by_rel, "by_rel");
+    TORCH_CHECK(sum_op >= 0 && sum_op <= 2 && mul_op >= 0 && mul_op <= 1, "ultra_mi: unknown sum/mul operator code");
     check_dense(input, "input", at::kFloat, input);
     check_dense(relation, "relation", at::kFloat, input);
     check_dense(output_grad, "output_grad", at::kFloat, input);
-    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
+    TORCH_CHECK(input.dim() == 2 && relation.dim() == 2 && input.size(1) == relation.size(1) && input.size(0) == n_src,
+                "ultra_mi::rspmm_plan_bwd: relation (R, F) and input (n_src = ", n_src, ", F) expected, got ", relation.sizes(),
+                " and ", input.sizes());
     const int64_t F = input.size(1), n_rel = relation.size(0);
+    TORCH_CHECK(output_grad.dim() == 2 && output_grad.size(0) == n_dst && output_grad.size(1) == F,
+                "ultra_mi::rspmm_plan_bwd: output_grad must be (", n_dst, ", ", F, "), got ", output_grad.sizes());
+    TORCH_CHECK(!s_src || (s_src->n_rows == n_src), "ultra_mi::rspmm_plan_bwd: by_src plan has ", s_src ? s_src->n_rows : 0,
+                " rows, n_src is ", n_src);
+    TORCH_CHECK(!s_rel || (s_rel->n_rows == n_rel), "ultra_mi::rspmm_plan_bwd: by_rel plan has ", s_rel ? s_rel->n_rows : 0,
+                " rows, relation has ", n_rel);
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
     Tensor rl = relation.contiguous(), x = input.contiguous(), g = output_grad.contiguous(), o;
-    if (output.has_value() && output->defined()) o = output->contiguous();
-    // d_input_add: the gradient the same rows receive from the layer's dense epilogue; accumulated IN PLACE (the kernels
-    // read every element before they write it), so no separate add pass and no extra (N, F) tensor
-    Tensor d_input, d_relation = s_rel ? at::empty_like(rl) : Tensor();
-    const float *add_ptr = nullptr;
-    if (s_src) {
-        if (d_input_add.has_value() && d_input_add->defined()) {
-            check_dense(*d_input_add, "d_input_add", at::kFloat, input);
-            TORCH_CHECK(d_input_add->sizes() == x.sizes() && d_input_add->is_contiguous(),
-                        "ultra_mi::rspmm_plan_bwd: d_input_add must be a contiguous tensor of the shape of input");
-            d_input = *d_input_add;
-            add_ptr = d_input.data_ptr<float>();
-        } else {
-            d_input = at::empty_like(x);
-        }
+    if (output.has_value() && output->defined()) {
+        check_dense(*output, "output", at::kFloat, input);
+        TORCH_CHECK(output->sizes() == output_grad.sizes(), "ultra_mi::rspmm_plan_bwd: output must have the shape of output_grad");
+        o = output->contiguous();
     }
-    if (F == 0 || (!s_src && !s_rel)) return {d_input, d_relation};
+    TORCH_CHECK(sum_op == 0 || o.defined(), "ultra_mi::rspmm_plan_bwd: min / max aggregation needs the forward output");
+    Tensor d_input, d_relation = s_rel ? at::empty_like(rl) : at::empty({0}, input.options());
+    if (s_src) {
+        TORCH_CHECK(d_input_out.has_value() && d_input_out->defined(), "ultra_mi::rspmm_plan_bwd: d_input (out) is required with by_src");
+        check_dense(*d_input_out, "d_input", at::kFloat, input);
+        TORCH_CHECK(d_input_out->sizes() == x.sizes() && d_input_out->is_contiguous(),
+                    "ultra_mi::rspmm_plan_bwd: d_input must be a contiguous tensor of the shape of input");
+        TORCH_CHECK(!accumulate || sum_op == 0, "ultra_mi::rspmm_plan_bwd: accumulate is for sum aggregation");
+        d_input = *d_input_out;
+    }
+    if (F == 0 || (!s_src && !s_rel)) return d_relation;
     const size_t ws_bytes = std::max(s_src ? ultra_rspmm_workspace_bytes(s_src, F) : 0,
                                      s_rel ? ultra_rspmm_workspace_bytes(s_rel, F) : 0);
     Tensor ws = at::empty({(int64_t)std::max<size_t>(ws_bytes / 4, 1)}, input.options());
     check_status(ultra_rspmm_backward_accumulate_f32(s_src, s_rel, rl.data_ptr<float>(), x.data_ptr<float>(),
-                                                     o.defined() ? o.data_ptr<float>() : nullptr, g.data_ptr<float>(), add_ptr,
+                                                     o.defined() ? o.data_ptr<float>() : nullptr, g.data_ptr<float>(),
+                                                     (s_src && accumulate) ? d_input.data_ptr<float>() : nullptr,
                                                      d_input.defined() ? d_input.data_ptr<float>() : nullptr,
-                                                     d_relation.defined() ? d_relation.data_ptr<float>() : nullptr,
+                                                     s_rel ? d_relation.data_ptr<float>() : nullptr,
                                                      ws.data_ptr<float>(), ws_bytes, n_src, n_dst, n_rel, F, (int)sum_op,
                                                      (int)mul_op, current_stream(input)),
                  "ultra_rspmm_backward_accumulate_f32");
-    return {d_input.defined() ? d_input : at::empty({0}, input.options()),
-            d_relation.defined() ? d_relation : at::empty({0}, input.options())};
+    return d_relation;
+}
+
+// ================================================================================================ CPU dispatch key
+// (host kernels of the three raw-CSR operators; same schemas, same checks, same results as the HIP ones in the
+// reference's summation order)
+void check_host(const Tensor &t, const char *name, at::ScalarType dtype) {
+    TORCH_CHECK(t.device().is_cpu(), "ultra_mi (CPU): ", name, " is on ", t.device(), "; all tensors of one call must share a device");
+    TORCH_CHECK(t.scalar_type() == dtype, "ultra_mi: ", name, " has dtype ", t.scalar_type(), ", expected ", dtype);
+}
+
+std::vector<Tensor> build_relcsr_cpu(const Tensor &edge_list, const optional<Tensor> &edge_weight, int64_t num_node,
+                                     int64_t num_relation) {
+    TORCH_CHECK(edge_list.dim() == 2 && edge_list.size(1) == 3, "build_relcsr: edge_list must be (E, 3) rows of "
+                "(node_in, node_out, relation), got ", edge_list.sizes());
+    check_host(edge_list, "edge_list", at::kLong);
+    const int64_t n_in = edge_list.size(0), n_rel = std::max<int64_t>(num_relation, 1);
+    TORCH_CHECK((double)num_node * (double)num_node * (double)n_rel < 9.0e18, "build_relcsr: adjacency too large for a 64-bit key");
+    Tensor el = edge_list.contiguous();
+    const int64_t *e = el.data_ptr<int64_t>();
+    Tensor weight;
+    if (edge_weight.has_value() && edge_weight->defined()) {
+        check_host(*edge_weight, "edge_weight", at::kFloat);
+        TORCH_CHECK(edge_weight->numel() == n_in, "build_relcsr: one weight per edge expected");
+        weight = edge_weight->contiguous();
+    }
+    const float *w_in = weight.defined() ? weight.data_ptr<float>() : nullptr;
+    // coalesce(): stable sort by (destination = node_out, source = node_in, relation); duplicates of one triple merge
+    // by adding their weights in input order
+    Tensor key = at::empty({n_in}, el.options());
+    int64_t *k = key.data_ptr<int64_t>();
+    for (int64_t i = 0; i < n_in; ++i) {
+        const int64_t src = e[3 * i], dst = e[3 * i + 1], rel = e[3 * i + 2];
+        TORCH_CHECK(src >= 0 && src < num_node && dst >= 0 && dst < num_node && rel >= 0 && rel < n_rel,
+                    "build_relcsr: edge ", i, " = (", src, ", ", dst, ", ", rel, ") is out of range");
+        k[i] = (dst * num_node + src) * n_rel + rel;
+    }
+    auto sorted = at::sort(key, /*stable=*/true, 0, false);
+    const int64_t *sk = std::get<0>(sorted).data_ptr<int64_t>(), *order = std::get<1>(sorted).data_ptr<int64_t>();
+    auto i32 = el.options().dtype(at::kInt);
+    Tensor out_src = at::empty({n_in}, i32), out_rel = at::empty({n_in}, i32), out_w = at::empty({n_in}, el.options().dtype(at::kFloat));
+    Tensor row_ptr = at::zeros({num_node + 1}, i32), edge_of_input = at::empty({n_in}, el.options());
+    int *ps = out_src.data_ptr<int>(), *pr = out_rel.data_ptr<int>(), *rp = row_ptr.data_ptr<int>();
+    float *pw = out_w.data_ptr<float>();
+    int64_t *eoi = edge_of_input.data_ptr<int64_t>();
+    int64_t m = 0;
+    for (int64_t i = 0; i < n_in; ++i) {
+        const int64_t o = order[i];
+        const float wi = w_in ? w_in[o] : 1.0f;
+        if (i > 0 && sk[i] == sk[i - 1]) {
+            pw[m - 1] = pw[m - 1] + wi;
+        } else {
+            ps[m] = (int)e[3 * o];
+            pr[m] = (int)e[3 * o + 2];
+            pw[m] = wi;
+            rp[e[3 * o + 1] + 1] += 1;
+            ++m;
+        }
+        eoi[o] = m - 1;
+    }
+    for (int64_t v = 0; v < num_node; ++v) rp[v + 1] += rp[v];
+    return {row_ptr, out_src.narrow(0, 0, m).contiguous(), out_rel.narrow(0, 0, m).contiguous(),
+            out_w.narrow(0, 0, m).contiguous(), edge_of_input};
+}
+
+CsrArgs check_csr_cpu(const Tensor &row_ptr, const Tensor &src, const Tensor &rel, const optional<Tensor> &w,
+                      const Tensor &relation, const Tensor &input, int64_t sum_op, int64_t mul_op) {
+    TORCH_CHECK(sum_op >= 0 && sum_op <= 2 && mul_op >= 0 && mul_op <= 1, "ultra_mi: unknown sum/mul operator code");
+    TORCH_CHECK(input.dim() == 2 && relation.dim() == 2, "ultra_mi: relation and input must be 2-D");
+    TORCH_CHECK(relation.size(1) == input.size(1), "ultra_mi: Expect relation and input to have the same width, but found ",
+                relation.size(1), " and ", input.size(1));
+    check_host(input, "input", at::kFloat);
+    check_host(relation, "relation", at::kFloat);
+    check_host(row_ptr, "row_ptr", at::kInt);
+    check_host(src, "src", at::kInt);
+    check_host(rel, "rel", at::kInt);
+    TORCH_CHECK(row_ptr.dim() == 1 && row_ptr.numel() >= 1 && src.dim() == 1 && rel.sizes() == src.sizes(),
+                "ultra_mi: row_ptr (N + 1,), src (E,), rel (E,) expected");
+    if (w.has_value() && w->defined()) {
+        check_host(*w, "w", at::kFloat);
+        TORCH_CHECK(w->sizes() == src.sizes(), "ultra_mi: one weight per edge expected");
+    }
+    return {row_ptr.numel() - 1, src.numel(), relation.size(0), input.size(1)};
+}
+
+// the operator pair as compile-time constants: the column loops then vectorise (element-wise, no reassociation)
+template <int SUM> inline float reduce_op(float acc, float y) {
+    if (SUM == 0) return acc + y;
+    if (SUM == 1) return y < acc ? y : acc;      // keeps the accumulator unless the message is strictly better
+    return y > acc ? y : acc;
+}
+template <int MUL> inline float message_op(float r, float x) { return MUL == 0 ? r * x : r + x; }
+
+template <int SUM, int MUL, bool HAS_W>
+void rspmm_rows_cpu(const int *row_ptr, const int *src, const int *rel, const float *w, const float *relation, const float *x,
+                    float *out, int64_t n_rows, int64_t F) {
+    const float identity = SUM == 0 ? 0.0f : (SUM == 1 ? FLT_MAX : -FLT_MAX);       // NaryMin / NaryMax ::zero
+    // a task = one destination row x one slab of up to 256 columns: a hub row's edges are walked by several threads
+    const int64_t slab = 256, n_slab = (F + slab - 1) / slab;
+    at::parallel_for(0, n_rows * n_slab, 1, [&](int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; ++t) {
+            const int64_t v = t / n_slab, f0 = (t % n_slab) * slab, f1 = std::min(F, f0 + slab);
+            float *__restrict__ o = out + v * F;
+            for (int64_t f = f0; f < f1; ++f) o[f] = identity;
+            for (int64_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) {
+                const float *__restrict__ xr = x + (int64_t)src[k] * F;
+                const float *__restrict__ rr = relation + (int64_t)rel[k] * F;
+                const float wk = HAS_W ? w[k] : 1.0f;
+                for (int64_t f = f0; f < f1; ++f) {
+                    const float y = wk * message_op<MUL>(rr[f], xr[f]);
+                    o[f] = reduce_op<SUM>(o[f], y);
+                }
+            }
+        }
+    });
+}
+
+Tensor rspmm_fwd_cpu(const Tensor &row_ptr, const Tensor &src, const Tensor &rel, const optional<Tensor> &w,
+                     const Tensor &relation, const Tensor &input, int64_t sum_op, int64_t mul_op) {
+    const CsrArgs a = check_csr_cpu(row_ptr, src, rel, w, relation, input, sum_op, mul_op);
+    Tensor rp = row_ptr.contiguous(), s = src.contiguous(), r = rel.contiguous(), rl = relation.contiguous(),
+           x = input.contiguous(), wt;
+    if (w.has_value() && w->defined()) wt = w->contiguous();
+    Tensor out = at::empty({a.n_rows, a.F}, input.options());
+    if (out.numel() == 0) return out;
+    const float *wp = wt.defined() ? wt.data_ptr<float>() : nullptr;
+#define ULTRA_CPU_FWD(S, M)                                                                                              \
+    (wp ? rspmm_rows_cpu<S, M, true>(rp.data_ptr<int>(), s.data_ptr<int>(), r.data_ptr<int>(), wp, rl.data_ptr<float>(),  \
+                                     x.data_ptr<float>(), out.data_ptr<float>(), a.n_rows, a.F)                          \
+        : rspmm_rows_cpu<S, M, false>(rp.data_ptr<int>(), s.data_ptr<int>(), r.data_ptr<int>(), wp, rl.data_ptr<float>(), \
+                                      x.data_ptr<float>(), out.data_ptr<float>(), a.n_rows, a.F))
+    switch (sum_op * 2 + mul_op) {
+        case 0: ULTRA_CPU_FWD(0, 0); break;
+        case 1: ULTRA_CPU_FWD(0, 1); break;
+        case 2: ULTRA_CPU_FWD(1, 0); break;
+        case 3: ULTRA_CPU_FWD(1, 1); break;
+        case 4: ULTRA_CPU_FWD(2, 0); break;
+        default: ULTRA_CPU_FWD(2, 1); break;
+    }
+#undef ULTRA_CPU_FWD
+    return out;
+}
+
+// Backward on the host: the reference's sequential sweep over the CSR (`d_input[src] += ...`, `d_relation[rel] += ...`
+// edge after edge in sorted order), made race-free by giving every thread its own slab of COLUMNS -- each element of
+// either gradient is still accumulated by one thread in CSR order.  Per edge and element
+//     contribution = ((g * [out == y]) * w) * d(rel (*|+) x)/d{x, rel}        ([.] only for min / max; every tie is fed)
+template <int SUM, int MUL, bool HAS_W>
+void rspmm_sweep_backward_cpu(const int *row_ptr, const int *src, const int *rel, const float *w, const float *relation,
+                              const float *x, const float *out, const float *g, float *d_rel, float *d_x, int64_t n_rows,
+                              int64_t F) {
+    const int64_t slab = 64, n_slab = (F + slab - 1) / slab;
+    at::parallel_for(0, n_slab, 1, [&](int64_t s0, int64_t s1) {
+        for (int64_t sl = s0; sl < s1; ++sl) {
+            const int64_t f0 = sl * slab, f1 = std::min(F, f0 + slab);
+            for (int64_t v = 0; v < n_rows; ++v) {
+                const float *__restrict__ gr = g + v * F;
+                const float *__restrict__ orow = out ? out + v * F : nullptr;
+                for (int64_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) {
+                    const float *__restrict__ xr = x + (int64_t)src[k] * F;
+                    const float *__restrict__ rr = relation + (int64_t)rel[k] * F;
+                    float *__restrict__ dx = d_x + (int64_t)src[k] * F;
+                    float *__restrict__ dr = d_rel + (int64_t)rel[k] * F;
+                    const float wk = HAS_W ? w[k] : 1.0f;
+                    for (int64_t f = f0; f < f1; ++f) {
+                        float gm = gr[f];
+                        if (SUM != 0) gm = gm * ((orow[f] == wk * message_op<MUL>(rr[f], xr[f])) ? 1.0f : 0.0f);
+                        const float gw = gm * wk;
+                        dx[f] = dx[f] + gw * (MUL == 0 ? rr[f] : 1.0f);
+                        dr[f] = dr[f] + gw * (MUL == 0 ? xr[f] : 1.0f);
+                    }
+                }
+            }
+        }
+    });
+}
+
+std::tuple<Tensor, Tensor> rspmm_bwd_cpu(const Tensor &row_ptr, const Tensor &src, const Tensor &rel,
+                                         const optional<Tensor> &w, const Tensor &relation, const Tensor &input,
+                                         const Tensor &output, const Tensor &output_grad, int64_t sum_op, int64_t mul_op) {
+    const CsrArgs a = check_csr_cpu(row_ptr, src, rel, w, relation, input, sum_op, mul_op);
+    check_host(output_grad, "output_grad", at::kFloat);
+    TORCH_CHECK(output_grad.dim() == 2 && output_grad.size(0) == a.n_rows && output_grad.size(1) == a.F,
+                "ultra_mi::rspmm_bwd: output_grad must be (", a.n_rows, ", ", a.F, ")");
+    if (sum_op != 0) {
+        check_host(output, "output", at::kFloat);
+        TORCH_CHECK(output.sizes() == output_grad.sizes(), "ultra_mi::rspmm_bwd: output must have the shape of output_grad");
+    }
+    Tensor d_relation = at::zeros_like(relation, at::MemoryFormat::Contiguous);
+    Tensor d_input = at::zeros_like(input, at::MemoryFormat::Contiguous);
+    if (a.n_edges == 0 || a.F == 0) return {d_relation, d_input};
+    Tensor rp = row_ptr.contiguous(), s = src.contiguous(), r = rel.contiguous(), rl = relation.contiguous(),
+           x = input.contiguous(), g = output_grad.contiguous(), o, wt;
+    if (sum_op != 0) o = output.contiguous();
+    if (w.has_value() && w->defined()) wt = w->contiguous();
+    const float *wp = wt.defined() ? wt.data_ptr<float>() : nullptr;
+    const float *op = o.defined() ? o.data_ptr<float>() : nullptr;
+#define ULTRA_CPU_BWD(S, M)                                                                                                  \
+    (wp ? rspmm_sweep_backward_cpu<S, M, true>(rp.data_ptr<int>(), s.data_ptr<int>(), r.data_ptr<int>(), wp,                 \
+                                               rl.data_ptr<float>(), x.data_ptr<float>(), op, g.data_ptr<float>(),           \
+                                               d_relation.data_ptr<float>(), d_input.data_ptr<float>(), a.n_rows, a.F)       \
+        : rspmm_sweep_backward_cpu<S, M, false>(rp.data_ptr<int>(), s.data_ptr<int>(), r.data_ptr<int>(), wp,                \
+                                                rl.data_ptr<float>(), x.data_ptr<float>(), op, g.data_ptr<float>(),          \
+                                                d_relation.data_ptr<float>(), d_input.data_ptr<float>(), a.n_rows, a.F))
+    switch (sum_op * 2 + mul_op) {
+        case 0: ULTRA_CPU_BWD(0, 0); break;
+        case 1: ULTRA_CPU_BWD(0, 1); break;
+        case 2: ULTRA_CPU_BWD(1, 0); break;
+        case 3: ULTRA_CPU_BWD(1, 1); break;
+        case 4: ULTRA_CPU_BWD(2, 0); break;
+        default: ULTRA_CPU_BWD(2, 1); break;
+    }
+#undef ULTRA_CPU_BWD
+    return {d_relation, d_input};
 }
 
 }  // namespace
@@ -371,7 +605,7 @@ TORCH_LIBRARY(ultra_mi, m) {
     m.def("rspmm_plan_fwd(Tensor plan, Tensor relation, Tensor input, Tensor? add_rows, Tensor? boundary_node, "
           "Tensor? boundary_value, int n_src, int sum_op, int mul_op) -> Tensor");
     m.def("rspmm_plan_bwd(Tensor? by_src, Tensor? by_rel, Tensor relation, Tensor input, Tensor? output, Tensor output_grad, "
-          "Tensor(a!)? d_input_add, int n_src, int n_dst, int sum_op, int mul_op) -> (Tensor, Tensor)");
+          "Tensor(a!)? d_input, bool accumulate, int n_src, int n_dst, int sum_op, int mul_op) -> Tensor");
     m.def("abi_version() -> int", []() -> int64_t { return ultra_rspmm_abi_version(); });
 }
 
@@ -380,6 +614,13 @@ TORCH_LIBRARY_IMPL(ultra_mi, CUDA, m) {
     m.impl("build_relcsr", build_relcsr);
     m.impl("rspmm_fwd", rspmm_fwd_hip);
     m.impl("rspmm_bwd", rspmm_bwd_hip);
+}
+
+// host kernels of the same three operators (config 1: `--gpus null`)
+TORCH_LIBRARY_IMPL(ultra_mi, CPU, m) {
+    m.impl("build_relcsr", build_relcsr_cpu);
+    m.impl("rspmm_fwd", rspmm_fwd_cpu);
+    m.impl("rspmm_bwd", rspmm_bwd_cpu);
 }
 
 // the plan tensor lives on the CPU while the dense operands live on the device: no single backend key fits

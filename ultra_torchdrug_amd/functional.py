@@ -6,9 +6,13 @@ Same name, argument order, keyword names and error behaviour (unknown operator n
 shape/device problems raise ``RuntimeError``).  Extension: ``sparse`` may be a cached :class:`RelCSR` instead of
 a 3-D sparse COO tensor, so the sort torchdrug repeats on every call happens once per graph.
 
-Everything numerical happens in ``libultra_rspmm.so``; this module only validates, allocates outputs with
-torch and passes raw pointers plus the current HIP stream across the C ABI.  CPU tensors are rejected: there is
-no fallback (the CPU oracle under ``oracle/`` is test infrastructure and is never imported from here).
+Everything numerical happens in native code; this module only validates, allocates outputs with torch and passes raw
+pointers plus the current HIP stream across the C ABI of ``libultra_rspmm.so``.  CPU tensors (the reference's
+``--gpus null`` runs, ``/root/reference/README.md:79,90``) go to the CPU kernels of the same dispatcher operators
+(``torch.ops.ultra_mi.rspmm_fwd / rspmm_bwd``, ``csrc/torch_ext.cpp``): the operator itself, in the reference's
+sequential order; the fused / plan-based extras of this module (boundary epilogue, frontier, fused layers, device-side
+ranking and sampling) are MI355X-only and raise on CPU tensors.  Without the native libraries every operator raises: there
+is no Python or PyTorch fallback, and the CPU oracle under ``oracle/`` is test infrastructure that is never imported here.
 """
 import collections
 
@@ -56,7 +60,7 @@ def _as_relcsr(sparse):
     return hit[0], (sparse if sparse.requires_grad else None)
 
 
-def _check_dense(csr, relation, input):
+def _check_dense(csr, relation, input, require_hip=True):
     n_dst, n_src, n_rel = csr.shape
     if input.dim() != 2 or relation.dim() != 2:
         raise RuntimeError("relation and input must be 2-D, got %s and %s" % (tuple(relation.shape), tuple(input.shape)))
@@ -69,9 +73,10 @@ def _check_dense(csr, relation, input):
                            % (relation.shape[1], input.shape[1]))
     if input.dtype != torch.float32 or relation.dtype != torch.float32:
         raise RuntimeError("rspmm is fp32 only (TF32 is disabled in the reference, script/run_full.py:19-20)")
-    if not input.is_cuda or not relation.is_cuda:
-        raise RuntimeError("ultra_torchdrug_amd.generalized_rspmm runs on an MI355X (HIP) device only; "
-                           "got input on %s, relation on %s. There is no CPU fallback." % (input.device, relation.device))
+    if require_hip and (not input.is_cuda or not relation.is_cuda):
+        raise RuntimeError("this operator of ultra_torchdrug_amd runs on an MI355X (HIP) device only; "
+                           "got input on %s, relation on %s (only generalized_rspmm has CPU kernels)"
+                           % (input.device, relation.device))
     if input.device != relation.device or input.device != csr.device:
         raise RuntimeError("sparse, relation and input must be on one device (%s, %s, %s)"
                            % (csr.device, relation.device, input.device))
@@ -169,7 +174,8 @@ def rspmm_forward_csr(row_ptr, src, rel, weight, relation, input, sum="add", mul
 
 
 def frontier_supported(sum, mul, F):
-    """The first-layer shortcut holds where a zero source row contributes exactly +-0: summed DistMult messages."""
+    """The first-layer shortcut holds where a zero source row contributes exactly +-0: summed DistMult messages with a
+    FINITE relation table (``inf * 0 = NaN`` in the full kernels; the caller tests the table, ``layer._frontier_tables_finite``)."""
     return sum == "add" and mul == "mul" and F % 64 == 0
 
 
@@ -177,7 +183,9 @@ def rspmm_frontier(csr, relation, boundary):
     """``rspmm_forward(csr, relation, <dense boundary>, "add", "mul", boundary=boundary)`` for the FIRST Bellman-Ford
     layer, whose input is the boundary itself (``ultra/model.py:116-120``): zero outside row ``node[b]`` of query block
     ``b``.  Visits only the out-edges of the boundary nodes; same bits as the full kernels (see ``csrc/frontier.inc``).
-    ``boundary = (node int32 (B,), value fp32 (B, 64))``; forward only."""
+    ``boundary = (node int32 (B,), value fp32 (B, 64))``; forward only.  Precondition: ``relation`` is finite -- an
+    ``inf`` / ``NaN`` entry reaches only the destinations of the boundary nodes' out-edges here, every destination of an
+    edge of that relation in the full kernel (``tests/test_frontier_sampler_gpu.py::test_frontier_non_finite_*``)."""
     b_node, b_value = boundary
     b_value = b_value.contiguous()
     n_dst, n_src, n_rel = csr.shape
@@ -222,10 +230,10 @@ def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mu
     by_src = csr.by_src if need_input else None
     by_rel = csr.by_rel if need_relation else None
     if _torch_ext.binding() == "torch":
-        d_in, d_rel = _torch_ext.load().rspmm_plan_bwd(
+        d_rel = _torch_ext.load().rspmm_plan_bwd(
             by_src.plan_tensor if by_src is not None else None, by_rel.plan_tensor if by_rel is not None else None,
-            relation, input, output, output_grad, d_input_add, csr.shape[1], csr.shape[0], sum_op, mul_op)
-        return (d_in if need_input else None), (d_rel if need_relation else None)
+            relation, input, output, output_grad, d_input, d_input_add is not None, csr.shape[1], csr.shape[0], sum_op, mul_op)
+        return d_input, (d_rel if need_relation else None)
     lib = _lib.load()
     n_ws = max(by_src.n_pieces if by_src is not None else 0, by_rel.n_pieces if by_rel is not None else 0) * F
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
@@ -432,6 +440,14 @@ def filtered_rank(pred, target, filt_ptr=None, filt_node=None):
 def remove_triples(graph, h, t, r, n_base_rel):
     """``graph`` (with inverse edges) minus the edges ``(h, t, r)`` / ``(t, h, r + n_base_rel)``, as zero weights on its
     cached plans: ``remove_easy_edges`` (``ultra/model.py:57-74``) for summed messages, natively and capturable."""
+    if not graph.edge_list.is_cuda:
+        # host graphs: the same zero weights from sorted triple keys (no device plans to patch)
+        n, rels = graph.num_node, graph.num_relation
+        h, t, r = h.reshape(-1), t.reshape(-1), r.reshape(-1)
+        gone = torch.cat([(h * n + t) * rels + r, (t * n + h) * rels + r + n_base_rel])
+        e = graph.edge_list
+        keep = ~torch.isin((e[:, 0] * n + e[:, 1]) * rels + e[:, 2], gone)
+        return graph.reweighted(graph.edge_weight * keep)
     return graph.without_triples(h, t, r, n_base_rel)
 
 
@@ -718,6 +734,13 @@ def rspmm_sum_plus(sparse, relation, input, add_rows, mul="mul", boundary=None):
     return _RSPMMFunction.apply(sparse_leaf, relation, input, csr, "add", mul, add_rows)
 
 
+def _rspmm_host(csr, relation, input, sum_op, mul_op):
+    """CPU tensors: the raw-CSR dispatcher operator (CPU key of ``torch.ops.ultra_mi.rspmm_fwd``; its Autograd key
+    reaches ``rspmm_bwd``'s CPU kernel).  Every row strictly sequentially in (src, rel) order: the reference's order."""
+    row_ptr, src, rel, w = csr.csr_arrays
+    return _torch_ext.load().rspmm_fwd(row_ptr, src, rel, w, relation, input, sum_op, mul_op)
+
+
 def generalized_rspmm(sparse, relation, input, sum="add", mul="mul"):
     r"""Generalized relational sparse-dense product (drop-in for torchdrug's function of the same name).
 
@@ -736,6 +759,12 @@ def generalized_rspmm(sparse, relation, input, sum="add", mul="mul"):
         input = input.unsqueeze(-1)
         if relation.dim() == 1:
             relation = relation.unsqueeze(-1)
-    _check_dense(csr, relation, input)
-    out = _RSPMMFunction.apply(sparse_leaf, relation, input, csr, sum, mul)
+    _check_dense(csr, relation, input, require_hip=False)
+    if not input.is_cuda:
+        if sparse_leaf is not None:
+            raise RuntimeError("generalized_rspmm on CPU tensors has no gradient for the sparse values "
+                               "(the reference takes its scatter path then, ultra/layer.py:299)")
+        out = _rspmm_host(csr, relation, input, *_ops(sum, mul))
+    else:
+        out = _RSPMMFunction.apply(sparse_leaf, relation, input, csr, sum, mul)
     return out.squeeze(-1) if squeeze else out

@@ -23,6 +23,18 @@ from . import backend
 FRONTIER_FIRST_LAYER = True
 
 
+def _frontier_tables_finite(relation_input):
+    """The shortcut's precondition.  ``w * (rel * 0)`` is ``+-0`` only for a FINITE relation entry: the full kernels turn an
+    ``inf`` / ``NaN`` entry of the relation table into ``NaN`` at every destination of an edge of that relation (``inf * 0``),
+    the frontier kernel never visits those edges.  Eager calls therefore test the table (one tiny reduction + a host
+    read, like the reference's own per-call index asserts, ``ultra/model.py:174-175``) and send a non-finite table
+    through the full kernel -- the reference's semantics.  While a hipGraph is being captured no host read is possible:
+    a captured step assumes finite tables, as it assumes valid indices (the capture's eager warm-up calls do test them)."""
+    if relation_input.is_cuda and torch.cuda.is_current_stream_capturing():
+        return True
+    return bool(torch.isfinite(relation_input).all())
+
+
 class _TallLinear(torch.autograd.Function):
     """``F.linear`` whose weight gradient is reduced in row slices.  The relation projections see ``B * R`` rows (7 584 for
     an FB15k237-sized vocabulary at B = 16) and 64 outputs: ``d_weight = grad^T . input`` is then a 64 x 64 GEMM with
@@ -270,7 +282,8 @@ class _RelationalConvBase(nn.Module):
         bound_args = dict(add_rows=boundary) if sparse_bound is None else dict(boundary=sparse_bound)
         if kind in ("sum", "mean"):
             if (fuse_bound and input_is_boundary and sparse_bound is not None and FRONTIER_FIRST_LAYER
-                    and ops.frontier_supported("add", mul, input.shape[1]) and sparse_bound[1].shape[-1] == 64):
+                    and ops.frontier_supported("add", mul, input.shape[1]) and sparse_bound[1].shape[-1] == 64
+                    and _frontier_tables_finite(relation_input)):
                 # first layer: only the out-edges of the boundary rows carry non-zero messages (csrc/frontier.inc)
                 update = ops.rspmm_frontier(adjacency, relation_input, sparse_bound)
             elif fuse_bound:

@@ -520,6 +520,21 @@ class RelCSR:
         other._by_rel = plans[2].with_weight_buffer(w[2])
         return other
 
+    @property
+    def csr_arrays(self):
+        """The coalesced adjacency as the raw-CSR operators of ``torch.ops.ultra_mi`` take it: ``(row_ptr int32 (n_dst +
+        1,), src int32 (E,), rel int32 (E,), w fp32 (E,) | None)``, rows in (src, rel) order.  Cached; a re-weighted
+        RelCSR shares the index arrays of its base."""
+        base = getattr(self, "_base", None) or self
+        if getattr(base, "_csr_index", None) is None:
+            n_dst = base.shape[0]
+            row_ptr = torch.zeros(n_dst + 1, dtype=torch.long, device=base.device)
+            if base.n_edges:
+                torch.cumsum(torch.bincount(base.dst, minlength=n_dst), 0, out=row_ptr[1:])
+            base._csr_index = (row_ptr.to(torch.int32).contiguous(), base.src.to(torch.int32).contiguous(),
+                               base.rel_id.to(torch.int32).contiguous())
+        return base._csr_index + (None if self.unit_weight else self.weight.contiguous(),)
+
     def degree_in(self):
         """Weighted in-degree per destination row (``graph.degree_out`` of the transposed adjacency)."""
         out = torch.zeros(self.shape[0], dtype=torch.float32, device=self.device)
