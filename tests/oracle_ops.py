@@ -168,8 +168,9 @@ class OracleFunctional:
         return candidates[index]
 
     @staticmethod
-    def filtered_rank_keys(pred, target, keys, anchor, rel, n_rel):
+    def filtered_rank_keys(pred, target, keys, anchor, rel, n_rel, n_node=None):
         """task.py:307-315 with the dense mask of task.py:65-100 rebuilt from the keys."""
+        assert n_node is None or n_node == pred.shape[1]
         rows, n_node = pred.shape
         mask = np.ones((rows, n_node), dtype=bool)
         if keys is not None:

@@ -86,8 +86,53 @@ def _worker(rank, world, port, out_dir):
     both = [torch.zeros_like(finals["flat"]) for _ in range(world)]
     dist.all_gather(both, finals["overlap"])
     assert torch.equal(both[0], both[1])
+    # a backward under paused() fires no hook; reduce_all() then packs from the gradients of THAT backward (what a
+    # graph replay followed by reduce_all() relies on), and a second backward without finish() is refused
+    twin, _ = _build()
+    twin.train()
+    reducer = engine.GradientReducer(twin, overlap=True)
+    with oracle_rspmm(0):
+        twin._static_negative = torch.randint(0, 120, (8, 8), generator=torch.Generator().manual_seed(50 + rank))
+        stale, _ = twin(triples[200 + 8 * rank: 208 + 8 * rank])
+        twin.zero_grad()
+        stale.backward()                                    # hooks live: every bucket is in flight ...
+        assert reducer._from_hooks == len(reducer.buckets)
+        reducer.finish()                                    # ... and retired
+        assert reducer.launched_from_hooks == len(reducer.buckets)
+        twin.zero_grad()
+        fresh, _ = twin(triples[300 + 8 * rank: 308 + 8 * rank])
+        with reducer.paused():
+            fresh.backward()
+        assert reducer._from_hooks == 0
+        local = torch.cat([p.grad.reshape(-1).clone() for b in reducer.buckets for p in b["params"]])
+        reducer.reduce_all()
+        reduced = torch.cat([p.grad.reshape(-1) for b in reducer.buckets for p in b["params"]])
+        both_local = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(both_local, local)
+        assert torch.allclose(reduced, (both_local[0] + both_local[1]) / 2, rtol=0, atol=1e-7)     # the NEW gradients
+        again, _ = twin(triples[300 + 8 * rank: 308 + 8 * rank])
+        again.backward()
+        more, _ = twin(triples[300 + 8 * rank: 308 + 8 * rank])
+        with pytest.raises(RuntimeError, match="second backward"):
+            more.backward()
+        reducer.abandon()
+        reducer.remove_hooks()
+
+    # multi-graph evaluation (ultra/engine.py:100-159): per-graph loop, metrics averaged over the graphs
+    multi, _ = _build()
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    other, n2, r2 = synthetic_triples((90, 500, 4), 11)
+    multi.add_context("second", Graph(torch.from_numpy(other), num_node=n2, num_relation=r2))
+    multi.eval()
+    sets = {"default": triples[:21], "second": torch.from_numpy(other[:13])}
+    with oracle_rspmm(0):
+        mean, per_graph, rankings = engine.evaluate_all(multi, sets, batch_size=8)
+    assert multi.split == "default" and rankings["default"].shape == (21, 2) and rankings["second"].shape == (13, 2)
     torch.save(dict(ranking=ranking, mrr=metric["mrr"], loss=loss, tloss=tmetric["binary cross entropy"],
-                    unused=unused, grads=grads), os.path.join(out_dir, "rank%d.pt" % rank))
+                    unused=unused, grads=grads, multi_mean=mean, multi_rankings=rankings,
+                    multi_mrr={k: float(v["mrr"]) for k, v in per_graph.items()}),
+               os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -114,6 +159,21 @@ def test_two_rank_evaluate_and_train_step(tmp_path):
     assert any(k.startswith("rel_models.0.model.mlp") for k in r0["unused"])
     assert torch.equal(r0["grads"], r1["grads"]) and torch.isfinite(r0["grads"]).all()
     assert abs(float(r0["tloss"]) - float(r1["tloss"])) < 1e-7     # packed metric reduce: same mean on both ranks
+    # evaluate_all: both ranks hold every graph's full ranking; the mean is the unweighted mean over the graphs
+    for name in ("default", "second"):
+        assert torch.equal(r0["multi_rankings"][name], r1["multi_rankings"][name])
+        want_mrr = float((1.0 / r0["multi_rankings"][name].float()).mean())
+        assert abs(r0["multi_mrr"][name] - want_mrr) < 1e-6
+    assert abs(r0["multi_mean"]["mrr"] - (r0["multi_mrr"]["default"] + r0["multi_mrr"]["second"]) / 2) < 1e-9
+    assert r0["multi_mean"] == r1["multi_mean"]
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    other, n2, r2 = synthetic_triples((90, 500, 4), 11)
+    task.add_context("second", Graph(torch.from_numpy(other), num_node=n2, num_relation=r2)).copy()
+    with torch.no_grad(), oracle_rspmm(0):
+        task.use("second")
+        want2 = torch.cat([task.rank_batch(torch.from_numpy(other[:13])[i:i + 8]) for i in range(0, 13, 8)])
+    assert torch.equal(r0["multi_rankings"]["second"], want2)
 
 
 def test_gather_variable_single_process():

@@ -70,6 +70,21 @@ def gather_variable(local):
     return out
 
 
+def validate_triples(task, triples):
+    """Range check of ``(h, t, r)`` rows against the active context, ONCE per evaluation run / captured step (one host
+    read).  The device kernels behind a hipGraph replay cannot raise: the frontier kernel reads ``src_ptr[h]``, the rank
+    kernel ``pred[target]`` and the key searches assume ``r < num_relation`` -- an id from another split's vocabulary
+    would read out of bounds silently (the reference's eager path fails in an index kernel instead)."""
+    if len(triples) == 0:
+        return triples
+    n, r = task.num_entity, task.num_relation
+    lo, hi_node, hi_rel = int(triples.min()), int(triples[:, :2].max()), int(triples[:, 2].max())
+    if lo < 0 or hi_node >= n or hi_rel >= r:
+        raise ValueError("triples out of range for context `%s` (%d entities, %d relations): min id %d, max entity %d, "
+                         "max relation %d" % (task.split, n, r, lo, hi_node, hi_rel))
+    return triples
+
+
 class GraphedPredict:
     """``task.predict`` for a fixed batch size as ONE hipGraph: an evaluation batch is ~250 small launches
     (18 rspmm + epilogues + relation projections + score MLP) whose host-side issue cost exceeds their GPU time
@@ -80,7 +95,7 @@ class GraphedPredict:
     def __init__(self, task, example_batch, warmup=3):
         assert example_batch.is_cuda and not task.training
         self.task = task
-        self.static_batch = example_batch.clone()
+        self.static_batch = validate_triples(task, example_batch).clone()
         model = task.model
         model.check_indices = False
         try:
@@ -109,22 +124,33 @@ class GraphedPredict:
 
 class GraphedTrainStep:
     """One fine-tuning step (``ultra/engine.py:62-92``) for a fixed batch size as ONE hipGraph: strict negative
-    sampling, removal of the batch's own edges, forward and backward.  A step is ~800 launches, most of them tiny, and
-    their host-side issue cost exceeds the GPU time of the kernels.  Nothing in the step has a data-dependent shape any
-    more: the negatives come from the sorted completion keys (``ultra_strict_negative``) and the edge removal from a
-    binary search in the plans (``ultra_edge_removal_weights``), where the reference builds ``(B / 2, N)`` masks,
-    calls ``nonzero`` and re-sorts a new graph (task.py:102-118, model.py:57-74).  The gradient all-reduce and the
-    optimizer step follow the replay eagerly (``train_step`` semantics).  Models the native removal does not cover
+    sampling, removal of the batch's own edges, forward, backward -- and, with a :class:`GradientReducer`, the bucketed
+    gradient all-reduce.  A step is ~800 launches, most of them tiny, and their host-side issue cost exceeds the GPU time
+    of the kernels.  Nothing in the step has a data-dependent shape any more: the negatives come from the sorted
+    completion keys (``ultra_strict_negative``) and the edge removal from a binary search in the plans
+    (``ultra_edge_removal_weights``), where the reference builds ``(B / 2, N)`` masks, calls ``nonzero`` and re-sorts a new
+    graph (task.py:102-118, model.py:57-74).
+
+    Overlap under replay (BASELINE north star: "all-reduce ... overlapped with the next layer's rspmm on a side HIP
+    stream").  The reducer's ``post_accumulate_grad`` hooks fire DURING the captured backward: each bucket's pack lands
+    on the capturing stream, its RCCL all-reduce on the reducer's side stream (forked from the capturing stream by an
+    event wait, so it becomes a parallel branch of the captured graph), and ``reducer.finish()`` -- also captured --
+    joins the branch and unpacks.  A replay therefore runs the same fork / collective / join structure as an eager
+    ``train_step``: the collective nodes depend only on their bucket's pack, not on the rspmm backward kernels of the
+    layers that follow.  ``reduce_in_graph`` tells whether that capture succeeded; if the runtime refuses to capture
+    the collectives, the step is captured without them and the same buckets go out right after each replay (no
+    overlap, same numbers).  The optimizer step follows the replay eagerly.  Models the native removal does not cover
     (min / max / PNA aggregation, ``remove_one_hop``) keep eager steps: use :func:`train_step`."""
 
-    def __init__(self, task, optimizer, example_batch, warmup=3, reducer=None):
+    def __init__(self, task, optimizer, example_batch, warmup=3, reducer=None, reduce_in_graph=True):
         assert example_batch.is_cuda and task.training
         model = task.model
         if model.remove_one_hop or not model._removal_by_zero_weight(sums_only=True):
             raise ValueError("GraphedTrainStep needs summed messages and remove_one_hop=False (the edge removal that can "
                              "be captured); use engine.train_step for this model")
         self.task, self.optimizer, self.reducer = task, optimizer, reducer
-        self.static_batch = example_batch.clone()
+        self.static_batch = validate_triples(task, example_batch).clone()
+        self.reduce_in_graph = False
         model.check_indices = False
         try:
             side = torch.cuda.Stream()
@@ -134,25 +160,50 @@ class GraphedTrainStep:
                     optimizer.zero_grad(set_to_none=True)
                     loss, _ = task(self.static_batch)
                     loss.backward()
+                    if reducer is not None:         # whole steps: the hooks' collectives are waited for and unpacked, so
+                        reducer.finish()            # no bucket state survives into the capture (and RCCL is warm)
             torch.cuda.current_stream().wait_stream(side)
-            optimizer.zero_grad(set_to_none=True)   # the captured backward allocates the gradients in the graph's pool
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
-                self.static_loss, self.static_metric = task(self.static_batch)
-                self.static_loss.backward()
+            in_graph = reducer is not None and reduce_in_graph and reducer.overlap and reducer._active()
+            if in_graph:
+                try:
+                    self._capture(reduce=True)
+                    self.reduce_in_graph = True
+                except Exception as err:            # the runtime refused collective nodes: capture the step without them
+                    import warnings
+                    warnings.warn("GraphedTrainStep: capturing the gradient all-reduce failed (%s); the buckets are "
+                                  "reduced after each replay instead" % (str(err).splitlines()[0] if str(err) else type(err).__name__))
+                    torch.cuda.synchronize()
+                    reducer.abandon()
+            if not self.reduce_in_graph:
+                self._capture(reduce=False)
             self.last_negatives = task.last_negatives       # (B, num_negative): rewritten by every replay
         finally:
             model.check_indices = True
+
+    def _capture(self, reduce):
+        import contextlib
+        self.optimizer.zero_grad(set_to_none=True)  # the captured backward allocates the gradients in the graph's pool
+        self.graph = torch.cuda.CUDAGraph()
+        hooks = contextlib.nullcontext() if (reduce or self.reducer is None) else self.reducer.paused()
+        # thread_local: other threads of the process (the RCCL watchdog polls events) must not abort the capture
+        with hooks, torch.cuda.graph(self.graph, capture_error_mode="thread_local" if reduce else "relaxed"):
+            self.static_loss, self.static_metric = self.task(self.static_batch)
+            self.static_loss.backward()
+            if reduce:
+                self.reducer.finish()
 
     def __call__(self, batch):
         """One step on ``batch`` (same shape as the example): returns ``(loss, metrics averaged over ranks)``."""
         assert batch.shape == self.static_batch.shape
         self.static_batch.copy_(batch)
-        self.graph.replay()
-        if self.reducer is not None:
+        if self.reducer is not None and not self.reduce_in_graph:
+            with self.reducer.paused():             # (replays fire no hooks; this keeps it so by construction)
+                self.graph.replay()
             self.reducer.reduce_all()
         else:
-            allreduce_gradients(self.task)
+            self.graph.replay()
+            if self.reducer is None:
+                allreduce_gradients(self.task)
         self.optimizer.step()
         return self.static_loss.detach(), reduce_metrics(self.static_metric)
 
@@ -238,7 +289,8 @@ def _ranks_of_unique_queries(task, local, batch_size, graphed):
             pick = (entries < n) if side == 0 else (entries >= n)
             e = entries[pick]
             if len(e):
-                ranks[e] = ops.filtered_rank_keys(rows[pick], target[e], keys[side], anchor[e], base[e], rank_rel)
+                ranks[e] = ops.filtered_rank_keys(rows[pick], target[e], keys[side], anchor[e], base[e], rank_rel,
+                                                  graph.num_node)
     return torch.stack([ranks[:n], ranks[n:]], dim=1)
 
 
@@ -255,7 +307,7 @@ def evaluate(task, triples, batch_size=16, graphed=None, cache_relations=None, u
     same ranks, fewer Bellman-Ford passes on test sets whose triples share heads or tails."""
     device = task.device
     mine = shard_indices(len(triples))
-    local = triples[mine].to(device)
+    local = validate_triples(task, triples[mine].to(device))
     if graphed is None:
         graphed = device.type == "cuda" and len(local) >= 2 * batch_size and not task.training
     if cache_relations is None:
@@ -278,8 +330,39 @@ def evaluate(task, triples, batch_size=16, graphed=None, cache_relations=None, u
     finally:
         if cache_relations:
             task.clear_relation_cache()
+    if task.metric_per_rel:
+        # the reference's target() returns the relation of every ranked triple beside the masks (task.py:290-292) and
+        # evaluate() groups by it; one more column through the same gather
+        both = gather_variable(torch.cat([ranks, local[:, 2:3]], dim=1))
+        ranking = both[:, :2].contiguous()
+        return task.evaluate(ranking, rel=both[:, 2].contiguous()), ranking
     ranking = gather_variable(ranks)
     return task.evaluate(ranking), ranking
+
+
+@torch.no_grad()
+def evaluate_all(task, test_sets, batch_size=16, **kwargs):
+    """Evaluation of multi-graph pre-training (``ultra/engine.py:100-159``): ``test_sets`` maps a graph context of
+    ``task`` (``task.add_context``; the reference's ``graph_<id>``) to the ``(n, 3)`` triples of that graph's split; every
+    graph is evaluated in turn with :func:`evaluate` (query-sharded over the ranks, one int64 rank gather per graph --
+    the reference gathers each graph's score tensors) and the metrics are AVERAGED over the graphs with equal weight, as
+    the reference does (``:154-157``).  Contexts are visited in sorted name order, so all ranks issue the same sequence
+    of collectives.  Returns ``(mean metrics as floats, {graph: metrics}, {graph: ranking})``; the active context is
+    restored afterwards."""
+    if not test_sets:
+        raise ValueError("evaluate_all: no test sets")
+    saved = task.split
+    per_graph, rankings = {}, {}
+    try:
+        for name in sorted(test_sets, key=str):
+            task.use(name)
+            per_graph[str(name)], rankings[str(name)] = evaluate(task, test_sets[name], batch_size=batch_size, **kwargs)
+    finally:
+        if saved is not None:
+            task.use(saved)
+    names = list(per_graph[next(iter(per_graph))])
+    mean = {k: float(sum(float(m[k]) for m in per_graph.values())) / len(per_graph) for k in names}
+    return mean, per_graph, rankings
 
 
 def sample_edges_from_graph(task, batch_size, generator=None):
@@ -327,12 +410,15 @@ class GradientReducer:
     Buckets follow the order in which backward produces gradients: the score head first, then the entity layers last to
     first, then the relation-model layers last to first -- one bucket per layer (a layer's parameters become ready
     together, right after its rspmm backward).  A ``post_accumulate_grad`` hook per parameter counts a bucket down; when
-    the last gradient of a bucket exists the bucket is packed on the compute stream, and its all-reduce is enqueued on a
-    SIDE stream (RCCL runs it there while the compute stream continues with the next layer's rspmm backward).  Buckets
-    are always launched in bucket order, so every rank issues the same sequence of collectives even when ranks train on
-    different graphs (multi-graph pre-training, ``ultra/engine.py:23-34``).  ``finish()`` makes the compute stream wait
-    for the side stream and unpacks the averaged gradients; it must run before ``optimizer.step()``.
-    Parameters that never receive a gradient (``UNUSED_PARAMETER_MARKS``) are excluded statically."""
+    the last gradient of a bucket exists the bucket is packed on the compute stream into its PERSISTENT flat buffer
+    (allocated once: nothing is allocated or freed per step, so the same code is capturable into a hipGraph), and its
+    all-reduce is enqueued on a SIDE stream (RCCL runs it there while the compute stream continues with the next layer's
+    rspmm backward).  Buckets are always launched in bucket order, so every rank issues the same sequence of collectives
+    even when ranks train on different graphs (multi-graph pre-training, ``ultra/engine.py:23-34``).  ``finish()`` makes
+    the compute stream wait for the side stream and unpacks the averaged gradients; it must run before
+    ``optimizer.step()`` and after EVERY backward whose hooks were live (a backward without it leaves buckets in flight:
+    ``finish()`` refuses to start from such a state).  Parameters that never receive a gradient
+    (``UNUSED_PARAMETER_MARKS``) are excluded statically."""
 
     def __init__(self, module, average=True, overlap=True, single_rank=False):
         """``single_rank``: issue the collectives even in a one-rank group (a one-GPU box can then exercise the RCCL
@@ -364,6 +450,8 @@ class GradientReducer:
                 self._bucket_of[id(p)] = b
         self._side = None
         self._handles = []
+        self._paused = False
+        self.launched_from_hooks = 0            # buckets whose all-reduce a hook started (i.e. during backward), last step
         self._reset()
         if overlap:
             for bucket in self.buckets:
@@ -375,47 +463,81 @@ class GradientReducer:
         self._ready = [False] * len(self.buckets)
         self._next = 0
         self._launched = 0
+        self._from_hooks = 0
 
     def remove_hooks(self):
         for h in self._handles:
             h.remove()
         self._handles = []
 
+    def paused(self):
+        """Context in which the hooks do nothing (a backward whose gradients are reduced later by ``reduce_all()``, e.g.
+        the capture of a step whose collectives stay outside the graph)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            saved, self._paused = self._paused, True
+            try:
+                yield self
+            finally:
+                self._paused = saved
+        return ctx()
+
+    def abandon(self):
+        """Forget buckets in flight (after a failed capture: their work handles belong to a dead graph)."""
+        for bucket in self.buckets:
+            bucket["work"] = None
+        self._reset()
+
     # ------------------------------------------------------------------ hooks (autograd thread, during backward)
     def _active(self):
         return dist.is_initialized() and (get_world_size() > 1 or self.single_rank)
 
     def _on_grad(self, param):
-        if not self._active():
+        if self._paused or not self._active():
             return
         b = self._bucket_of[id(param)]
         self._pending[b] -= 1
+        if self._pending[b] < 0:
+            raise RuntimeError("GradientReducer: a second backward reached bucket `%s` before finish() -- call finish() "
+                               "after every backward (or run the backward under paused())" % self.buckets[b]["name"])
         if self._pending[b] == 0:
             self._ready[b] = True
             while self._next < len(self.buckets) and self._ready[self._next]:
                 self._launch(self._next)
                 self._next += 1
+                self._from_hooks += 1
 
     def _launch(self, b):
         bucket = self.buckets[b]
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket["params"]]
-        flat = torch.cat([g.reshape(-1) for g in grads])                    # packed on the compute stream
-        bucket["flat"] = flat
+        params = bucket["params"]
+        ref = next((p.grad for p in params if p.grad is not None), params[0])
+        flat = bucket["flat"]
+        if flat is None or flat.device != ref.device:
+            flat = bucket["flat"] = torch.empty(bucket["numel"], dtype=torch.float32, device=ref.device)
+        offset = 0
+        for p in params:                                                     # packed on the compute stream
+            n = p.numel()
+            if p.grad is not None:
+                flat[offset:offset + n].copy_(p.grad.reshape(-1))
+            else:
+                flat[offset:offset + n].zero_()
+            offset += n
         if flat.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=flat.device)
             self._side.wait_stream(torch.cuda.current_stream(flat.device))   # the pack must be complete
             with torch.cuda.stream(self._side):
                 bucket["work"] = dist.all_reduce(flat, async_op=True)        # RCCL, enqueued behind the side stream
-            flat.record_stream(self._side)
         else:
             bucket["work"] = dist.all_reduce(flat, async_op=True)
         self._launched += 1
 
     # ------------------------------------------------------------------ after backward, before optimizer.step()
     def finish(self):
-        """Wait for every bucket (launching those whose hooks did not fire: ``overlap=False`` or a graph replay) and
-        write the reduced gradients back.  Returns the number of fp32 elements reduced."""
+        """Wait for every bucket (launching those whose hooks did not fire: ``overlap=False``, ``paused()`` or a graph
+        replay) and write the reduced gradients back.  Returns the number of fp32 elements reduced."""
         world = get_world_size()
         if not self._active():
             self._reset()
@@ -427,7 +549,7 @@ class GradientReducer:
         for bucket in self.buckets:
             bucket["work"].wait()                                           # compute stream waits for the collective
             flat = bucket["flat"]
-            if self.average:
+            if self.average and world > 1:
                 flat /= world
             offset = 0
             for p in bucket["params"]:
@@ -438,7 +560,8 @@ class GradientReducer:
                     p.grad.copy_(flat[offset:offset + n].view_as(p.grad))
                 offset += n
             total += flat.numel()
-            bucket["flat"] = bucket["work"] = None
+            bucket["work"] = None
+        self.launched_from_hooks = self._from_hooks
         self._reset()
         return total
 

@@ -451,14 +451,20 @@ def remove_triples(graph, h, t, r, n_base_rel):
     return graph.without_triples(h, t, r, n_base_rel)
 
 
-def filtered_rank_keys(pred, target, keys, anchor, rel, n_rel):
+def filtered_rank_keys(pred, target, keys, anchor, rel, n_rel, n_node=None):
     """Filtered ranks of one prediction side without filter lists or masks: ``pred`` fp32 ``(B, N)`` (a strided view of
     the ``(B, 2, N)`` scores is fine), ``target`` / ``anchor`` / ``rel`` int64 ``(B,)``; ``keys``: the graph's sorted
     distinct completion keys of that side (``Graph.completion_keys``) or ``None`` for the unfiltered rank.  Returns
-    int64 ``(B,)``.  No host synchronisation (capturable)."""
+    int64 ``(B,)``.  No host synchronisation (capturable).  ``n_node``: the node count the keys were built with; a
+    mismatch with ``pred.shape[1]`` raises (the kernel decodes keys with the candidate count as stride)."""
     rows, n_cand = pred.shape
     if pred.dtype != torch.float32 or pred.stride(1) != 1 or not pred.is_cuda:
         raise RuntimeError("filtered_rank_keys: pred must be fp32 (B, N) with contiguous rows on the HIP device")
+    if n_node is not None and int(n_node) != n_cand:
+        # the keys were built as (anchor * n_rel + rel) * n_node + other: decoded with another stride the filter reads
+        # other candidates' scores (or past the row) without any error
+        raise RuntimeError("filtered_rank_keys: the scores list %d candidates but the completion keys were built over "
+                           "%d nodes (filter graph and fact graph must share the entity set)" % (n_cand, int(n_node)))
     for name, t in (("target", target), ("anchor", anchor), ("rel", rel)):
         if t.dtype != torch.int64 or t.shape != (rows,) or t.device != pred.device:
             raise RuntimeError("filtered_rank_keys: %s must be int64 (%d,) on %s" % (name, rows, pred.device))

@@ -80,6 +80,11 @@ class KnowledgeGraphCompletion(nn.Module):
         ``sample_weight`` degree tables are counted over (task.py:50-57)."""
         if fact_graph is None:
             fact_graph = graph if fact_mask is None else graph.edge_mask(fact_mask)
+        if fact_graph.num_node != graph.num_node:
+            # scores are indexed by the fact graph's entities, filters by the graph's: they must be one entity set
+            # (task.py:31-63, 539-581 -- every split of a dataset shares its vocabulary)
+            raise ValueError("context `%s`: the filter graph has %d nodes, the fact graph %d"
+                             % (name, graph.num_node, fact_graph.num_node))
         ctx = {"graph": graph, "fact_graph": fact_graph,
                "rel_graphs": [rel_model.construct_relation_graph(fact_graph) for rel_model in self.rel_models]}
         if self.sample_weight:
@@ -372,8 +377,8 @@ class KnowledgeGraphCompletion(nn.Module):
             keys = (graph.completion_keys(0), graph.completion_keys(1)) if self.filtered_ranking else (None, None)
             # the filter of each side is a range of the graph's sorted completion keys, found inside the kernel:
             # no (B, N) mask, no per-batch list building, no host synchronisation (capturable with predict)
-            t_rank = ops.filtered_rank_keys(pred[:, 0], pos_t_index, keys[0], pos_h_index, pos_r_index, n_rel)
-            h_rank = ops.filtered_rank_keys(pred[:, 1], pos_h_index, keys[1], pos_t_index, pos_r_index, n_rel)
+            t_rank = ops.filtered_rank_keys(pred[:, 0], pos_t_index, keys[0], pos_h_index, pos_r_index, n_rel, graph.num_node)
+            h_rank = ops.filtered_rank_keys(pred[:, 1], pos_h_index, keys[1], pos_t_index, pos_r_index, n_rel, graph.num_node)
             return torch.stack([t_rank, h_rank], dim=1)
         return self.get_ranking(pred, self.target(batch))
 
