@@ -9,28 +9,34 @@ edges), seeded random-init Ultra weights (6 x 64d entity stack + 6
 One STEP = one evaluation batch of B=16 test triples through ``predict`` (/root/reference/ultra/task.py:228-263):
 relation-graph Bellman-Ford (6 rspmm) + tail pass + head pass over all N candidates (the reference: 2 x 6 rspmm +
 epilogues + score MLP = 18 rspmm calls; here the tail and head queries share ONE 2B-wide Bellman-Ford, every score
-bit-identical: tests/test_model_gpu.py), replayed as one hipGraph.  Unit of work = one edge message = one edge x one
-batch element x 64 fp32 lanes; a step aggregates 12*E*B + 6*E_rel*B of them (sum of nnz * B over all
-rspmm calls).  All inputs are resident in HBM before the timed region.  Multi-GPU: every rank holds the graph and
-evaluates its own query batch (query sharding, no data-path collective) => weak scaling.
+bit-identical: tests/test_model_gpu.py), replayed as one hipGraph.  All inputs are resident in HBM before the timed
+region.  Multi-GPU: every rank holds the graph and evaluates its own query batch (query sharding, no data-path
+collective) => weak scaling; ``value`` = units of all ranks / max-over-ranks time.
 
-Reported beside ``value`` on the same line (every fraction can be recomputed from the numbers printed with it and
-from profiles/):
-* ``composition``      -- entity-graph and relation-graph edge messages per step and the entity-only rate; the step
-                          with and without the first-layer frontier shortcut; predict + filtered ranking per step.
-* ``roofline``         -- the dominant kernel of THIS workload (entity-graph forward, quad_kernel).  Its gathered
-                          matrix (119 MB) lives in L2 / Infinity Cache, so it is priced as what it is, an L2-gather
-                          kernel: algorithmic bytes per launch / launch time against the XCD-L2 peak (34.5 TB/s) and
-                          the guide's measured ceiling for rows gathered from L2 (16.8-18.8 TB/s), plus the HBM
-                          fraction on COMPULSORY bytes.  HIP events around exactly that kernel, on its stream.
-* ``roofline_hbm``     -- config 5 (S-stress, 10 M nodes / 100 M edges / 1 k relations, B = 1) AT SIZE: the
-                          DRAM-bound regime, algorithmic bytes against the 8 TB/s HBM peak ("S-stress
-                          is the roofline reference").
-* ``cpu_baseline``     -- the CPU oracle's row loop (restatement of the torchdrug CPU algorithm, kind "port") on all
-                          host cores, one rspmm call of the bench graph.
+What ``value`` counts (round 3).  Unit of work = one edge message = one ENTITY-graph edge x one
+query x 64 fp32 lanes that a kernel actually VISITS.  Per step: layers 2-6 walk all E edges for 2B queries
+(10 * E * B messages) and layer 1 -- whose input is the boundary, zero outside one row per query -- visits only the
+out-edges of the boundary nodes (the frontier kernel; ``config.frontier_edges_per_step``, counted exactly).  The
+relation-graph stack (a complete 474-node graph under the SURVEY 8d generator, LDS-resident, not a sparse-gather
+workload) is part of the step's TIME but not of ``value``; its rate is ``config.relation_graph_edges_per_s``.  The
+figure round 2 printed (all 12 * E * B + 6 * E_rel * B messages, visited or not) is ``config.value_r2_definition``.
+
+Driver-kept keys (the driver keeps metric / value / ... / config / roofline / cpu_baseline and only the NAMES of the
+rest), so everything a reader needs to check the headline sits in those three objects:
+* ``config``       -- workload, what ``value`` counts, per-rank times, and ``config.configs``: one timing per BASELINE
+                      config measured in THIS run (1: inductive v1 shape on the CPU kernels; 2: S-codexs inference;
+                      3: S-wn18rr operator fwd+bwd and fine-tune step, median + spread; 4: pretrain_3g-shaped B = 64
+                      step; 5: S-stress).
+* ``roofline``     -- SURVEY 8d's line: S-stress (10 M nodes / 100 M edges / 1 k relations, B = 1) AT SIZE, algorithmic
+                      bytes / HIP-event kernel time against the 8 TB/s HBM peak.  ``roofline.l2`` is the dominant kernel
+                      of the HEADLINE workload, whose gathered matrix (119 MB) is cache-resident: priced against the
+                      XCD-L2 peak, never against HBM (its algorithmic rate exceeds 8 TB/s).
+* ``cpu_baseline`` -- the CPU restatement (oracle row loop, rebuilt -O3 -march=native here, OpenMP, kind "port") on all
+                      host cores, one rspmm call of the headline graph at the GPU kernel's width F = 2 * B * 64.
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
 import sys
@@ -48,6 +54,12 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0
 L2_GATHER_CEILING_GBS = (16800.0, 18800.0)
+
+# FB15k237Inductive v1 (GraIL split) sizes [ULTRA paper's dataset table; the files are fetched at run time by the
+# reference, /root/reference/ultra/dataset.py:450-460]: relations, (entities, triples) of the training graph,
+# (entities, fact triples, valid, test) of the inference graph
+FB_V1 = dict(n_rel=180, train=(1594, 4245), inference=(1093, 1993, 206, 205))
+PRETRAIN_3G = ("S-fb15k237", "S-wn18rr", "S-codexm")
 
 
 class HipEvents:
@@ -98,48 +110,107 @@ def timed_kernel(lib, events, fn, n):
     return float(np.mean(ms)), len(ms)
 
 
-def cpu_baseline(graph_np, n_node, n_rel, F, budget_s=20.0):
-    """The oracle's CSR row loop (OpenMP over rows) on ONE rspmm call of the bench graph; rank 0, N=1 only."""
+def wall_ms(fn, n, warm=0):
+    """Host-clock time per call of ``fn(i)`` over n calls between two device synchronisations."""
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn(i)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / max(n, 1)
+
+
+def spread(samples):
+    """Median and spread of per-step times (ms): the fine-tune step moved between 7.9 and 11 ms over round 2's records."""
+    s = np.sort(np.asarray(samples, dtype=np.float64))
+    return {"n": int(len(s)), "median_ms": float(np.median(s)), "min_ms": float(s[0]), "max_ms": float(s[-1]),
+            "p10_ms": float(s[int(0.1 * (len(s) - 1))]), "p90_ms": float(s[int(round(0.9 * (len(s) - 1)))])}
+
+
+def host_cores():
+    """Cores in this process's affinity mask, capped by the cgroup's CPU quota where one is set."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(graph_np, n_node, n_rel, F, budget_s=24.0):
+    """The oracle's CSR row loop (OpenMP; rebuilt here with -O3 -march=native -ffp-contract=off) on ONE rspmm call of
+    the bench graph at the width of the GPU's launch; rank 0, N=1 only.  A GPU box's affinity mask may list more cores
+    than its share of the host grants, so a few OpenMP team sizes are timed and the FASTEST is reported with the thread
+    count it used (``cores``); every team size's median is in ``threads_tried``."""
     from oracle import oracle as O
-    threads = len(os.sched_getaffinity(0))           # all host cores this process may use
-    os.environ["OMP_NUM_THREADS"] = str(threads)
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     O.build()
+    try:
+        forward, build = O.native_forward_fn(), "gcc -O3 -march=native -ffp-contract=off -fopenmp (built on this host)"
+    except Exception as err:                         # no compiler on the box: the committed portable build
+        forward, build = O.rspmm_forward, "oracle/Makefile build (-O3, portable); native rebuild failed: %s" % err
     rng = np.random.default_rng(1024)
     csr = O.coalesce_csr(graph_np["dst"], graph_np["src"], graph_np["rel"], None, n_node, n_node, n_rel)
     relation = rng.standard_normal((n_rel, F)).astype(np.float32)
     x = rng.standard_normal((n_node, F)).astype(np.float32)
-    O.rspmm_forward(csr, relation, x, "add", "mul")            # warm-up (page-in, thread pool)
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 10 and (time.perf_counter() - t_start) < budget_s:
-        t0 = time.perf_counter()
-        O.rspmm_forward(csr, relation, x, "add", "mul")
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
+    forced = int(os.environ.get("ULTRA_BENCH_CPU_THREADS", "0"))
+    sizes = [forced] if forced else sorted({cores, min(cores, 128), min(cores, 64), min(cores, 32), min(cores, 16)}, reverse=True)
+    set_threads = getattr(forward, "set_threads", None)
+    if set_threads is None:
+        sizes = sizes[:1]
+    tried, best = {}, None
+    t_all = time.perf_counter()
+    for n_thr in sizes:
+        if set_threads is not None:
+            set_threads(n_thr)
+        forward(csr, relation, x, "add", "mul")                    # warm-up (page-in, thread pool)
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 10 and (time.perf_counter() - t_start) < budget_s / len(sizes):
+            t0 = time.perf_counter()
+            forward(csr, relation, x, "add", "mul")
+            times.append(time.perf_counter() - t0)
+        tried[str(n_thr)] = float(np.median(times))
+        if best is None or tried[str(n_thr)] < best[1]:
+            best = (n_thr, tried[str(n_thr)], len(times))
+    cpu_wall = time.perf_counter() - t_all
+    threads, med, n_calls = best
     # second CPU number (SURVEY 8d): the reference's own O(E) formulation (ultra/layer.py:249-255,275-276) in PyTorch
     torch.set_num_threads(threads)
     ti = torch.from_numpy(csr.col.astype(np.int64)); tr = torch.from_numpy(csr.rel.astype(np.int64))
     td = torch.from_numpy(csr.row.astype(np.int64))
-    tx, trel = torch.from_numpy(x), torch.from_numpy(relation)
+    Fm = min(F, 1024)                                          # (E, F) fp32 temporaries: 2.2 GB each at F = 1 024
+    tx, trel = torch.from_numpy(x[:, :Fm].copy()), torch.from_numpy(relation[:, :Fm].copy())
     t0 = time.perf_counter()
-    torch.zeros(n_node, F).index_add_(0, td, trel[tr] * tx[ti])
+    torch.zeros(n_node, Fm).index_add_(0, td, trel[tr] * tx[ti])
     t_torch = time.perf_counter() - t0
+    algo = bytes_algo(csr.n_edges, n_node, n_rel, F)
     return {"value": csr.n_edges * (F // 64) / med, "unit": "edges aggregated/s", "cores": threads,
-            "torch_materialised_value": csr.n_edges * (F // 64) / t_torch,
-            "kind": "port",
-            "sample": "%d x one rspmm forward (add,mul) on S-fb15k237, E=%d, F=%d (B=%d); median %.3f s; "
-                      "oracle/rspmm_oracle.c row loop, OpenMP, restatement of the torchdrug CPU algorithm"
-                      % (len(times), csr.n_edges, F, F // 64, med)}
+            "kind": "port", "algorithmic_GBps": algo / med / 1e9, "seconds_per_call": med, "F": F,
+            "threads_tried": tried, "affinity_cores": len(os.sched_getaffinity(0)),
+            "torch_materialised_value": csr.n_edges * (Fm // 64) / t_torch, "build": build,
+            "sample": "%d x one rspmm forward (add,mul) on S-fb15k237, E=%d, F=%d (the GPU launch's width: tail and head "
+                      "queries of B=%d) with %d OpenMP threads (fastest of the team sizes %s); median %.4f s; %.1f s of CPU-leg "
+                      "wall time in all; oracle/rspmm_oracle.c row loop (64-column x equal-edge row-range tasks), restatement of "
+                      "the torchdrug CPU algorithm" % (n_calls, csr.n_edges, F, F // 128, threads, sorted(int(k) for k in tried),
+                                                       med, cpu_wall)}
 
 
-def stress_traffic():
-    """HBM bytes per launch of the S-stress kernel from separate rocprofv3 --pmc passes of the same kernel and workload,
-    committed under profiles/ (not measured in this run)."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic_stress.json")
+def latest_profile(pattern):
+    """Newest committed PMC summary of a kind (profiles/rNN_<pattern>): measured in separate rocprofv3 --pmc passes of the
+    same kernel and workload, never in this run."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    if not paths:
+        return None, None
     try:
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch"), "profiles/r02_traffic_stress.json (rocprofv3 --pmc passes, not this run)"
-    except OSError:
+        with open(paths[-1]) as f:
+            return json.load(f), "profiles/%s (rocprofv3 --pmc passes, not this run)" % os.path.basename(paths[-1])
+    except (OSError, ValueError):
         return None, None
 
 
@@ -178,12 +249,192 @@ def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel
     algo = bytes_algo(E, n_node, R, F)
     kernel = "rowgroup_kernel<add,mul,unit_w,624 of 1000 relation rows from LDS>" if plan.row_ptr is not None and plan.n_pieces == 0 \
         else "packed_kernel<FWD,add,mul,unit_w,VAR 2>"
+    tj, tsrc = latest_profile("traffic_stress.json")
     return {"bound": "hbm", "workload": "S-stress N=%d E=%d R=%d B=1 F=64 (input %.2f GB)" % (n_node, E, R, n_node * F * 4 / 1e9),
             "kernel": kernel, "launches_timed": n, "kernel_ms": ms, "algorithmic_bytes": algo,
+            "bytes_per_unit": algo / E,
             "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": stress_traffic()[0],
-            "traffic_source": stress_traffic()[1],
-            "edges_per_s": E / (ms * 1e-3), "chunked_kernel_ms": ms_chunked, "plan_build_s": build_s}
+            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": tj.get("hbm_bytes_per_launch") if tj else None, "traffic_source": tsrc,
+            "edges_per_s": E / (ms * 1e-3), "chunked_kernel_ms": ms_chunked, "plan_build_s": build_s,
+            "timed": "HIP events recorded by the library around the kernel, on the kernel's stream, %d launches" % n}
+
+
+# ------------------------------------------------------------------------------------------------ tasks of a shape
+def transductive_task(workload, dev, n_test, seed):
+    """Fact graph of exactly the shape's triples + ``n_test`` held-out DISTINCT triples of the same distribution (never
+    edges of the message-passing graph, but part of ``graph``, which the ranking is filtered against: the transductive
+    protocol, task.py:31-63); seeded random-init weights."""
+    from ultra_torchdrug_amd.data import SHAPES, synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    n_node, n_fact, n_rel = SHAPES[workload]
+    triples, _, _ = synthetic_triples((n_node, n_fact + n_test, n_rel), seed, alpha=0.0 if workload == "S-stress" else 1.0)
+    fact_mask = np.zeros(len(triples), dtype=bool)
+    fact_mask[:n_fact] = True
+    torch.manual_seed(seed)
+    task = build_ultra(n_rel)
+    task.preprocess(Graph(torch.from_numpy(triples), num_node=n_node, num_relation=n_rel), torch.from_numpy(fact_mask))
+    task.to(dev).eval()
+    return task, triples, fact_mask, n_fact
+
+
+def prepare_plans(task):
+    """Everything that is built once per graph, before any timed region."""
+    und = task.model._undirected(task.fact_graph)
+    for g in (und, task.rel_graphs[0]):
+        _ = g.relcsr.fwd
+        _ = g.relcsr.frontier_index
+    for g in (task.graph, task.fact_graph):
+        g.completion_keys(0), g.completion_keys(1)
+    return und
+
+
+def finetune_samples(task, facts, B, n_steps, seed, reducer=None):
+    """Per-step wall times (ms, device-synchronised) of the fine-tuning step replayed as one hipGraph
+    (engine.GraphedTrainStep): strict negatives, edge removal, forward, backward (+ the captured bucket all-reduces when a
+    reducer is given), AdamW.  The batches are drawn before the clock starts."""
+    from ultra_torchdrug_amd import engine
+    task.train()
+    opt = torch.optim.AdamW(task.parameters(), lr=5e-4)
+    pick = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    n_fact = len(facts)
+    idx = torch.from_numpy(pick.choice(n_fact, B, replace=False)).to(facts.device)
+    step = engine.GraphedTrainStep(task, opt, facts[idx], reducer=reducer)
+    batches = [facts[torch.from_numpy(pick.choice(n_fact, B, replace=False)).to(facts.device)] for _ in range(n_steps + 2)]
+    out = []
+    for i, batch in enumerate(batches):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(batch)
+        torch.cuda.synchronize()
+        if i >= 2:
+            out.append(1e3 * (time.perf_counter() - t0))
+    in_graph = step.reduce_in_graph
+    del step
+    task.eval()
+    return out, in_graph
+
+
+def config_timings(dev, lib, seed, B, quick):
+    """One timing per BASELINE.json config, measured in this run (rank 0, one GPU): the rows that were builder-run only."""
+    import ultra_torchdrug_amd as U
+    from ultra_torchdrug_amd import engine, functional as UF
+    from ultra_torchdrug_amd.data import synthetic_kg, synthetic_triples
+    from ultra_torchdrug_amd.engine import GraphedPredict
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    out = []
+    events = HipEvents(lib)
+
+    # ---- config 1: FB15k237Inductive-v1-shaped zero-shot inference on the CPU kernels (--gpus null)
+    r = FB_V1["n_rel"]
+    n_inf, t_fact, t_valid, t_test = FB_V1["inference"]
+    train, _, _ = synthetic_triples((FB_V1["train"][0], FB_V1["train"][1], r), seed)
+    inf, _, _ = synthetic_triples((n_inf, t_fact + t_valid + t_test, r), seed + 1)
+    torch.manual_seed(seed)
+    cpu_task = build_ultra(r)
+    g_train = Graph(torch.from_numpy(train), num_node=FB_V1["train"][0], num_relation=r)
+    cpu_task.preprocess_inductive(g_train, g_train, Graph(torch.from_numpy(inf[:t_fact]), num_node=n_inf, num_relation=r),
+                                  graph=g_train, inductive_graph=Graph(torch.from_numpy(inf), num_node=n_inf, num_relation=r))
+    cpu_task.eval().use("test")
+    test = torch.from_numpy(inf[t_fact + t_valid:])
+    torch.set_num_threads(host_cores())
+    with torch.no_grad():
+        cpu_task.rank_batch(test[:B])
+        t0 = time.perf_counter()
+        n_b = 0
+        for i in range(0, len(test) - B + 1, B):
+            cpu_task.rank_batch(test[i:i + B])
+            n_b += 1
+        cpu_ms = 1e3 * (time.perf_counter() - t0) / max(n_b, 1)
+    e_inf = 2 * t_fact
+    out.append({"config": 1, "name": "FB15k237Inductive v1-shaped zero-shot inference on CPU (--gpus null)",
+                "shape": "inference graph N=%d, %d fact triples (E=%d), R=%d; %d test triples, B=%d" % (n_inf, t_fact, e_inf, 2 * r, t_test, B),
+                "device": "cpu, %d torch threads; rspmm = CPU kernels of torch.ops.ultra_mi (csrc/torch_ext.cpp)" % torch.get_num_threads(),
+                "predict_plus_rank_ms_per_batch": cpu_ms,
+                "entity_edges_per_s": 12 * e_inf * B / (cpu_ms * 1e-3)})
+    del cpu_task
+
+    # ---- config 2: CoDExSmall-shaped transductive zero-shot inference, B = 16
+    task, triples, _, n_fact = transductive_task("S-codexs", dev, 512, seed)
+    und = prepare_plans(task)
+    test = torch.from_numpy(triples[n_fact:]).to(dev)
+    E, R2, N = und.relcsr.n_edges, und.num_relation, und.num_node
+    with torch.no_grad():
+        task.predict(test[:B])
+        replay = GraphedPredict(task, test[:B], warmup=0)
+        n_b = len(test) // B
+        step_ms = wall_ms(lambda i: replay(test[(i % n_b) * B:(i % n_b) * B + B]), 20 if quick else 100, warm=5)
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        xk, rk = torch.randn(N, 2 * B * 64, device=dev, generator=gen), torch.randn(R2, 2 * B * 64, device=dev, generator=gen)
+        for _ in range(3):
+            UF.rspmm_forward(und.relcsr, rk, xk, "add", "mul")
+        k_ms, _ = timed_kernel(lib, events, lambda: UF.rspmm_forward(und.relcsr, rk, xk, "add", "mul"), 20)
+    algo = bytes_algo(E, N, R2, 2 * B * 64)
+    out.append({"config": 2, "name": "CoDExSmall-shaped transductive zero-shot inference (rspmm fwd only)",
+                "shape": "S-codexs N=%d E=%d R=%d B=%d" % (N, E, R2, B),
+                "predict_ms_per_batch": step_ms, "entity_edges_visited_per_s": 10 * E * B / (step_ms * 1e-3),
+                "entity_fwd_kernel_us": 1e3 * k_ms, "entity_fwd_kernel_algorithmic_GBps": algo / (k_ms * 1e-3) / 1e9,
+                "entity_fwd_kernel_frac_of_l2_peak": algo / (k_ms * 1e-3) / 1e9 / L2_PEAK_GBS})
+    del task, replay, xk, rk
+    torch.cuda.empty_cache()
+
+    # ---- config 3: WN18RR-shaped fine-tuning, fp32, B = 16 (rspmm fwd + bwd through autograd, DistMult messages)
+    task, triples, _, n_fact = transductive_task("S-wn18rr", dev, 512, seed)
+    und = prepare_plans(task)
+    E, R2, N = und.relcsr.n_edges, und.num_relation, und.num_node
+    F = B * 64
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    xk, rk, gk = (torch.randn(N, F, device=dev, generator=gen), torch.randn(R2, F, device=dev, generator=gen),
+                  torch.randn(N, F, device=dev, generator=gen))
+    for _ in range(3):
+        UF.rspmm_forward(und.relcsr, rk, xk, "add", "mul")
+        UF.rspmm_backward(und.relcsr, rk, xk, None, gk, "add", "mul")
+    fwd_ms, _ = timed_kernel(lib, events, lambda: UF.rspmm_forward(und.relcsr, rk, xk, "add", "mul"), 20)
+    bwd_ms = wall_ms(lambda i: UF.rspmm_backward(und.relcsr, rk, xk, None, gk, "add", "mul"), 20, warm=3)
+    del xk, rk, gk
+    facts = torch.from_numpy(triples[:n_fact]).to(dev)
+    samples, _ = finetune_samples(task, facts, B, 10 if quick else 30, seed)
+    out.append({"config": 3, "name": "WN18RR-shaped fine-tuning fp32 (rspmm fwd+bwd autograd, DistMult message)",
+                "shape": "S-wn18rr N=%d E=%d R=%d B=%d, 128 strict negatives, AdamW" % (N, E, R2, B),
+                "operator_fwd_us": 1e3 * fwd_ms, "operator_bwd_us": 1e3 * bwd_ms,
+                "operator_fwd_bwd_edges_per_s": 3 * E * B / ((fwd_ms + bwd_ms) * 1e-3),
+                "finetune_step": spread(samples),
+                "finetune_launch": "one hipGraph replay per step (engine.GraphedTrainStep) + AdamW"})
+    del task, facts
+    torch.cuda.empty_cache()
+
+    # ---- config 4: pretrain_3g-shaped multi-graph step, B = 64 per GPU (ultra/engine.py:23-34, pretrain_3g.yaml:36-56)
+    torch.manual_seed(seed)
+    task = build_ultra(237)
+    for i, name in enumerate(PRETRAIN_3G):
+        task.add_context(str(i), synthetic_kg(name))
+    task.to(dev).train()
+    opt = torch.optim.AdamW(task.parameters(), lr=5e-4)
+    gen_cpu = torch.Generator().manual_seed(seed)
+    per_step, drawn = [], []
+    n_steps = 6 if quick else 12
+    for s in range(3 + n_steps):
+        batch, gid = engine.sample_edges_from_graph(task, 64, gen_cpu)
+        batch = batch.to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        engine.train_step(task, opt, (batch, gid))
+        torch.cuda.synchronize()
+        if s >= 3:
+            per_step.append(1e3 * (time.perf_counter() - t0))
+            drawn.append(gid)
+    out.append({"config": 4, "name": "pretrain_3g-shaped multi-graph step (FB15k237 + WN18RR + CoDEx-M shapes, one set of weights)",
+                "shape": "B=64 per GPU, 128 strict negatives, AdamW 5e-4; graph drawn per step with p ~ #fact edges",
+                "step": spread(per_step), "graphs_drawn": "".join(drawn),
+                "launch": "eager engine.train_step (each step may be on another graph)",
+                "note": "1 GPU here: the 8-GPU run of this config is the driver's SCALE job (no multi-GPU node was "
+                        "available to the builder; no scaling curve exists yet)"})
+    del task, opt
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -195,7 +446,8 @@ def main():
     ap.add_argument("--workload", default="S-fb15k237")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", dest="stress", action="store_false",
-                    help="skip config 5 at size (S-stress: 10 M nodes / 100 M edges, ~15 s) reported as roofline_hbm")
+                    help="skip config 5 at size (S-stress: 10 M nodes / 100 M edges, ~15 s); `roofline` is then the L2 line")
+    ap.add_argument("--no-configs", dest="configs", action="store_false", help="skip the per-config timings (config.configs)")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--mrr-queries", type=int, default=500,
                     help="seeded test triples ranked after the timed region (500 = the reference's fast_test, pretrain_3g.yaml:56)")
@@ -210,7 +462,7 @@ def main():
     share = os.environ.get("ULTRA_BENCH_SHARE_GPU") == "1"
     n_dev = torch.cuda.device_count()              # (does not initialise the GPU)
     if n_dev == 0:
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        raise SystemExit("bench.py needs an MI355X: the headline is the HIP path")
     if share:
         local_rank %= n_dev
     # the process group comes first: RCCL is initialised before this process makes any other GPU call
@@ -228,7 +480,7 @@ def main():
 
     import ultra_torchdrug_amd as U
     from ultra_torchdrug_amd import layer as UL
-    from ultra_torchdrug_amd.data import synthetic_triples, DEFAULT_SEED
+    from ultra_torchdrug_amd.data import DEFAULT_SEED
     from ultra_torchdrug_amd.graph import Graph
     from ultra_torchdrug_amd.task import build_ultra
     lib = U.require_library()
@@ -237,21 +489,10 @@ def main():
 
     # ---------------- graph, split, model (identical on every rank) ----------------
     from ultra_torchdrug_amd.data import SHAPES
-    n_node, n_fact, n_rel = SHAPES[args.workload]
-    n_test = min(2048, n_fact // 20)
-    # n_fact + n_test DISTINCT triples of the same distribution: the first n_fact are the fact graph (E = 2 * n_fact
-    # exactly, as BASELINE.md states), the rest are held-out test queries -- never edges of the message-passing graph,
-    # but part of `graph`, which the ranking is filtered against (the transductive protocol, task.py:31-63).
-    triples, _, _ = synthetic_triples((n_node, n_fact + n_test, n_rel), DEFAULT_SEED,
-                                      alpha=0.0 if args.workload == "S-stress" else 1.0)
-    fact_mask = np.zeros(len(triples), dtype=bool)
-    fact_mask[:n_fact] = True
+    n_node, n_fact_shape, n_rel = SHAPES[args.workload]
+    n_test = min(2048, n_fact_shape // 20)
+    task, triples, fact_mask, n_fact = transductive_task(args.workload, dev, n_test, DEFAULT_SEED)
     test_idx = np.arange(n_fact, n_fact + n_test)
-    graph = Graph(torch.from_numpy(triples), num_node=n_node, num_relation=n_rel)
-    torch.manual_seed(DEFAULT_SEED)
-    task = build_ultra(n_rel)
-    task.preprocess(graph, torch.from_numpy(fact_mask))
-    task.to(dev).eval()
     und = task.model._undirected(task.fact_graph)
     _ = und.relcsr.fwd                  # coalesce + sort + chunk schedule: once per graph (torchdrug: every rspmm call)
     torch.cuda.synchronize()
@@ -259,26 +500,29 @@ def main():
     _ = U.RelCSR.from_edge_list(und.edge_list, und.edge_weight, und.num_node, und.num_relation).fwd
     torch.cuda.synchronize()
     plan_build_ms = 1e3 * (time.perf_counter() - t_plan)
+    prepare_plans(task)
     E, R2 = und.relcsr.n_edges, und.num_relation
     E_rel = task.rel_graphs[0].relcsr.n_edges
-    for g in (und, task.rel_graphs[0]):
-        _ = g.relcsr.fwd                                      # plans built before the timed region
-        _ = g.relcsr.frontier_index
-    for g in (task.graph, task.fact_graph):
-        g.completion_keys(0), g.completion_keys(1)            # sorted filter keys: once per graph
     B = args.batch
     F = B * 64
     # predict() scores tails and heads in ONE Bellman-Ford over 2B queries (task.fuse_sides): 6 entity launches of
     # width 2F per step instead of 12 of width F -- the same edge messages
     Fk = 2 * F
-    entity_edges_per_step = 12 * E * B
-    rel_edges_per_step = 6 * E_rel * B
-    edges_per_step = entity_edges_per_step + rel_edges_per_step
+    full_layers_edges = 10 * E * B                       # layers 2..6: every edge, 2B queries
+    rel_edges_per_step = 6 * E_rel * B                   # round 2's count for the relation-graph stack (all six layers)
 
     # each rank evaluates its own strided shard of the seeded test triples (DistributedSampler-style)
     test = torch.from_numpy(triples[test_idx]).to(dev)
     shard = test[rank::world]
     n_batches = max(len(shard) // B, 1)
+    # layer 1 visits the out-edges of the boundary nodes only: counted exactly, per batch of the shard
+    deg_out = torch.bincount(und.relcsr.src, minlength=n_node)
+
+    def frontier_edges(batch):
+        h, t = batch[:, 0], batch[:, 1]
+        return int(deg_out[h].sum() + deg_out[t].sum())        # tail queries start at h, head queries (tail form) at t
+
+    frontier_per_batch = [frontier_edges(shard[b * B:b * B + B]) for b in range(n_batches)]
 
     # profile hook: HIP events around the entity-graph forward kernel (the dominant kernel), recorded by the library
     # on the kernel's own stream.  --eager: one pair per launch of the timed region.  Default (hipGraph replay): event
@@ -329,14 +573,6 @@ def main():
             same = same and bool(torch.equal(got, task.predict(batch)))
         return same
 
-    def time_steps(fn, n):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n):
-            fn(i)
-        torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / n
-
     with torch.no_grad():
         for i in range(args.warmup):
             step(i)
@@ -349,11 +585,13 @@ def main():
         for i in range(args.steps):
             step(args.warmup + i)
         torch.cuda.synchronize()
+        my_elapsed = time.perf_counter() - t0
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         state["on"] = False
+        frontier_visited = sum(frontier_per_batch[(args.warmup + i) % n_batches] for i in range(args.steps))
 
         # ---- after the timed region: the dominant kernel alone, and the other per-step numbers
         gen = torch.Generator(device=dev).manual_seed(DEFAULT_SEED)
@@ -373,23 +611,21 @@ def main():
             torch.cuda.synchronize()
         kernel_ms = events.elapsed_ms()
         n_side = min(args.steps, 50)
-        eager_ms = time_steps(lambda i: task.predict(shard[:B]), 5) if graphed is not None else 1e3 * elapsed / args.steps
+        eager_ms = wall_ms(lambda i: task.predict(shard[:B]), 5) if graphed is not None else 1e3 * elapsed / args.steps
         # predict + filtered ranking (what engine.evaluate does per batch): the ranks come from the sorted completion keys
         # on the device, nothing but (B, 2) int64 leaves it
-        rank_ms = time_steps(lambda i: task.rank_batch(shard[:B], pred=step(i)), n_side)
+        rank_ms = wall_ms(lambda i: task.rank_batch(shard[:B], pred=step(i)), n_side)
         # the same step without the first-layer frontier shortcut (every layer walks all E edges)
         UL.FRONTIER_FIRST_LAYER = False
         try:
             plain = None if args.eager else capture()
-            for i in range(5):
-                step(i, plain)
-            no_frontier_ms = time_steps(lambda i: step(i, plain), n_side)
+            no_frontier_ms = wall_ms(lambda i: step(i, plain), n_side, warm=5)
         finally:
             UL.FRONTIER_FIRST_LAYER = True
         frontier_ms, _ = timed_kernel(lib, events, lambda: UF.rspmm_frontier(und.relcsr, rk, bk), 10)
         # the same step with the relation representations of all R relations computed once per evaluation run
         # (task.cache_relation_representations, what engine.evaluate does): identical scores, the relation stack leaves
-        # the per-batch path.  Reported beside `value`, never as `value`.
+        # the per-batch path.
         torch.cuda.synchronize()
         t_c = time.perf_counter()
         task.cache_relation_representations(B)
@@ -397,35 +633,37 @@ def main():
         cache_build_ms = 1e3 * (time.perf_counter() - t_c)
         try:
             cached = None if args.eager else capture()
-            for i in range(5):
-                step(i, cached)
-            cached_ms = time_steps(lambda i: step(i, cached), n_side)
+            cached_ms = wall_ms(lambda i: step(i, cached), n_side, warm=5)
             replay_same_cached = replays_equal_eager(cached)
         finally:
             task.clear_relation_cache()
         replay_same = replays_equal_eager(graphed)
+        # the relation-graph stack alone (what the step spends outside the entity graph and the score head)
+        rel_ms = wall_ms(lambda i: task.relation_representations(shard[:B, 2]), 20, warm=3)
     UF.rspmm_forward = real_forward
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
+    # per-rank times (the driver computes scaling efficiency from `value`; this shows which rank set the max)
+    t_mine = torch.tensor([my_elapsed], dtype=torch.float64, device="cpu" if share else dev)
+    per_rank = [t_mine.clone() for _ in range(world)]
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    # fabric bytes per launch of the dominant kernel: separate rocprofv3 --pmc passes of the same kernel and workload
-    # (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction), committed under profiles/ -- not measured in this run
-    traffic, traffic_source = None, None
-    for name in ("r02_traffic_fwd_fb15k237.json", "traffic_fwd_fb15k237.json"):
-        tpath = os.path.join(ROOT, "profiles", name)
-        if args.workload == "S-fb15k237" and args.batch == 16 and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("F") == Fk:
-                traffic, traffic_source = tj.get("hbm_bytes_per_launch"), "profiles/%s (rocprofv3 --pmc passes, not this run)" % name
-                break
+        dist.all_gather(per_rank, t_mine)
+    per_rank_ms = [1e3 * float(t.item()) / args.steps for t in per_rank]
+    t = torch.tensor([elapsed, float(frontier_visited)], dtype=torch.float64, device="cpu" if share else dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, frontier_all = float(tmax[0].item()), float(tsum[1].item())
+    else:
+        frontier_all = float(frontier_visited)
 
     k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     algo = bytes_algo(E, n_node, R2, Fk)
     compulsory = bytes_min(E, n_node, R2, Fk)
     achieved = algo / (k_avg_ms * 1e-3) / 1e9
+    tj, traffic_source = latest_profile("traffic_fwd_fb15k237.json")
+    traffic = tj.get("hbm_bytes_per_launch") if (tj and tj.get("F") == Fk and args.workload == "S-fb15k237") else None
 
     # ---------------- MRR (after the timed region): HIP path, and HIP vs CPU-oracle path on the same weights --------
     def mrr_of(t, queries):
@@ -434,7 +672,8 @@ def main():
         return rk
 
     def oracle_check(label):
-        """First batch once more with the CPU oracle in place of every HIP kernel (checker, never the product)."""
+        """First batch once more with the CPU oracle in place of every HIP kernel (checker, never the product; the gated
+        form of this check is tests/test_baseline_configs_gpu.py)."""
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_ops import oracle_rspmm
         cpu_task = build_ultra(n_rel)
@@ -481,7 +720,7 @@ def main():
     mrr = mrr_tuned = None
     metrics = metrics_tuned = None
     mrr_check = []
-    train_ms = None
+    train = None
     if args.mrr_queries > 0:
         # the seeded test triples are strided over the ranks; one all_gather of (n, 2) int64 ranks
         nq = min(-(-args.mrr_queries // world), len(test) // world)       # the same count on every rank
@@ -500,29 +739,11 @@ def main():
         if check:
             mrr_check.append(oracle_check("seeded random init (td_ultra_3g/4g.pth are missing blobs)"))
         if rank == 0 and world == 1 and args.finetune_steps > 0:
-            # a short seeded fine-tuning run (config 3's step: rspmm fwd+bwd, AdamW 5e-4, 128 strict negatives) so that
-            # the parity check also sees trained weights and an MRR that is not the random-init one
-            from ultra_torchdrug_amd import engine
-            task.train()
-            opt = torch.optim.AdamW(task.parameters(), lr=5e-4)
+            # a short seeded fine-tuning run (config 3's step on this graph: rspmm fwd+bwd, AdamW 5e-4, 128 strict
+            # negatives) so that the parity check also sees trained weights and an MRR that is not the random-init one
             facts = torch.from_numpy(triples[:n_fact]).to(dev)
-            pick = np.random.default_rng(DEFAULT_SEED)
-            torch.manual_seed(DEFAULT_SEED)
-            # the whole step (strict negatives, edge removal, forward, backward) replays as one hipGraph
-            idx = torch.from_numpy(pick.choice(n_fact, B, replace=False)).to(dev)
-            graphed_step = engine.GraphedTrainStep(task, opt, facts[idx])
-            # the batches of all steps are drawn before the clock starts (a host-side draw without replacement over
-            # 272 k facts costs more than the step)
-            batches = [facts[torch.from_numpy(pick.choice(n_fact, B, replace=False)).to(dev)]
-                       for _ in range(args.finetune_steps)]
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for batch in batches:
-                graphed_step(batch)
-            torch.cuda.synchronize()
-            train_ms = 1e3 * (time.perf_counter() - t1) / args.finetune_steps
-            del graphed_step
-            task.eval()
+            samples, _ = finetune_samples(task, facts, B, args.finetune_steps, DEFAULT_SEED)
+            train = spread(samples)
             metrics_tuned = metrics_of(gathered(mrr_of(task, shard[:nq])))
             mrr_tuned = metrics_tuned["mrr"]
             if check:
@@ -530,9 +751,36 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
+        visited = full_layers_edges * args.steps * world + frontier_all        # entity-graph messages visited, all ranks
+        l2_line = {"bound": "l2-gather", "kernel": "quad_kernel<FWD,add,mul,unit_w,8>", "workload": args.workload,
+                   "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
+                   "algorithmic_bytes": algo, "kernel_ms": k_avg_ms, "launches_timed": len(kernel_ms),
+                   "l2_gather_ceiling": list(L2_GATHER_CEILING_GBS),
+                   "frac_of_l2_gather_ceiling": achieved / L2_GATHER_CEILING_GBS[1],
+                   "hbm_compulsory_bytes": compulsory,
+                   "hbm_frac_on_compulsory_bytes": compulsory / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "traffic": traffic, "traffic_source": traffic_source if traffic else None,
+                   "note": "the gathered matrix (%.0f MB) is L2 / Infinity-Cache resident: its algorithmic rate exceeds the "
+                           "HBM peak (%.1f TB/s), so it is priced against the XCD-L2 peak (MI355X_MICROARCH.md: 34.5 TB/s; "
+                           "measured ceiling for rows gathered from L2: 16.8-18.8 TB/s); not an HBM-roofline workload "
+                           "(SURVEY 8d)" % (n_node * Fk * 4 / 1e6, achieved / 1e3)}
+        configs = []
+        roofline = dict(l2_line)
+        if world == 1:
+            del xk, rk
+            torch.cuda.empty_cache()
+            if args.configs:
+                configs = config_timings(dev, lib, DEFAULT_SEED, B, quick=args.steps < 100)
+            if args.stress:
+                roofline = stress_roofline(dev, lib)
+                roofline["l2"] = l2_line
+                configs.append({"config": 5, "name": "Synthetic KG 10M nodes / 100M edges / 1k relations, 64d inference (HBM-roofline stress)",
+                                "shape": roofline["workload"], "operator_fwd_ms": roofline["kernel_ms"],
+                                "edges_per_s": roofline["edges_per_s"], "frac_of_hbm_peak": roofline["frac"],
+                                "plan_build_s": roofline["plan_build_s"]})
         result = {
             "metric": "edges aggregated/sec, FB15k237-shaped 6L x 64d rspmm Bellman-Ford (predict: 18 rspmm/batch)",
-            "value": edges_per_step * args.steps * world / elapsed,
+            "value": visited / elapsed,
             "unit": "edges aggregated/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -543,39 +791,39 @@ def main():
                        "global_batch": B * world, "parallelism": "query-sharded replicas x%d" % world,
                        "launch": "eager" if graphed is None else "one hipGraph replay per step (engine.GraphedPredict)",
                        "device": "%s, %d CUs" % (torch.cuda.get_device_name(dev),
-                                                 torch.cuda.get_device_properties(dev).multi_processor_count)},
-            "edges_per_step": edges_per_step,
+                                                 torch.cuda.get_device_properties(dev).multi_processor_count),
+                       "value_counts": "ENTITY-graph edge messages the kernels visit: 10*E*B per step (layers 2-6, 2B queries) "
+                                       "+ the boundary nodes' out-edges in layer 1 (frontier kernel), over the WHOLE step time "
+                                       "(relation stack and score head included in the time, not in the count)",
+                       "entity_edges_visited_per_step": visited / (args.steps * world),
+                       "frontier_edges_per_step": frontier_all / (args.steps * world),
+                       "relation_graph_edges_per_step": rel_edges_per_step,
+                       "relation_stack_ms_per_step": rel_ms,
+                       "relation_graph_edges_per_s": rel_edges_per_step / (rel_ms * 1e-3),
+                       "value_r2_definition": (12 * E * B + rel_edges_per_step) * args.steps * world / elapsed,
+                       "per_rank_ms_per_step": per_rank_ms,
+                       "per_rank_value": [(full_layers_edges + frontier_all / (args.steps * world)) / (m * 1e-3) for m in per_rank_ms],
+                       "configs": configs},
+            "roofline": roofline,
             "composition": {
-                "entity_graph_edges_per_step": entity_edges_per_step,
-                "relation_graph_edges_per_step": rel_edges_per_step,
+                "ms_per_step_without_first_layer_frontier": no_frontier_ms,
+                "value_all_layers_full_kernel": 12 * E * B * world / (no_frontier_ms * 1e-3),
+                "first_layer_frontier_kernel_ms": frontier_ms,
+                "ms_per_step_with_cached_relation_representations": cached_ms,
+                "value_with_cached_relation_representations":
+                    (visited / (args.steps * world)) / (cached_ms * 1e-3) if cached_ms else None,
+                "relation_cache_build_ms": cache_build_ms,
+                "evaluate_test_set": eval_runs,
+                "graph_replays_identical_to_eager": {"per_batch_relations": replay_same, "cached_relations": replay_same_cached},
                 "relation_graph_note": "E_rel = %d over %d relation nodes and 4 edge types: with independently drawn Zipf "
                                        "heads / tails / relations (SURVEY 8d generator) every pair of relations co-occurs, "
                                        "so the relation graph is complete -- LDS-resident, not a sparse-gather workload"
                                        % (E_rel, R2),
-                "value_entity_only": entity_edges_per_step * args.steps * world / elapsed,
-                "ms_per_step_without_first_layer_frontier": no_frontier_ms,
-                "value_without_first_layer_frontier": edges_per_step * world / (no_frontier_ms * 1e-3),
-                "first_layer_frontier_kernel_ms": frontier_ms,
-                "ms_per_step_with_cached_relation_representations": cached_ms,
-                "value_entity_only_with_cached_relation_representations":
-                    entity_edges_per_step / (cached_ms * 1e-3) if cached_ms else None,
-                "relation_cache_build_ms": cache_build_ms,
-                "evaluate_test_set": eval_runs,
-                "graph_replays_identical_to_eager": {"per_batch_relations": replay_same, "cached_relations": replay_same_cached},
-                "relation_cache_note": "opt-in (engine.evaluate default for long runs): the relation representations of a "
-                                       "query depend on its relation only, so all R tables are computed once per "
-                                       "evaluation run and a batch picks its rows -- bit-identical scores "
-                                       "(tests/test_model_gpu.py); the relation-graph edge messages are then no longer "
-                                       "aggregated per batch, so this line reports the entity-graph rate only",
-                "first_layer_note": "layer 1 reads the boundary (zero outside one row per query): its E * B edge messages are "
-                                    "+-0 except on the out-edges of the boundary nodes; the frontier kernel adds exactly "
-                                    "those, bit-identically (tests/test_frontier_sampler_gpu.py); `value` counts the "
-                                    "layer's edges as aggregated either way",
                 "predict_plus_filtered_rank_ms_per_step": rank_ms,
-                "value_predict_plus_rank": edges_per_step * world / (rank_ms * 1e-3),
-                "finetune_ms_per_step": train_ms,
+                "finetune_step": train,
                 "finetune_note": "config 3's step on this graph (B = %d, 128 strict negatives, AdamW): negatives, edge removal, "
-                                 "forward and backward replayed as one hipGraph (engine.GraphedTrainStep)" % B,
+                                 "forward and backward replayed as one hipGraph (engine.GraphedTrainStep); per-step wall "
+                                 "times, device-synchronised" % B,
             },
             "plan_build_ms": plan_build_ms,
             "eager_ms_per_step": eager_ms,
@@ -585,18 +833,6 @@ def main():
                                            "%d eager launches of the same kernel/shapes right after the timed region "
                                            "(event records cannot be captured into the hipGraph with this HIP runtime)" % len(kernel_ms),
                                   "edges_per_s": E * (Fk // 64) / (k_avg_ms * 1e-3) if kernel_ms else None},
-            "roofline": {"bound": "l2-gather", "kernel": "quad_kernel<FWD,add,mul,unit_w,8>",
-                         "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
-                         "algorithmic_bytes": algo, "kernel_ms": k_avg_ms,
-                         "l2_gather_ceiling": list(L2_GATHER_CEILING_GBS),
-                         "frac_of_l2_gather_ceiling": achieved / L2_GATHER_CEILING_GBS[1],
-                         "hbm_compulsory_bytes": compulsory,
-                         "hbm_frac_on_compulsory_bytes": compulsory / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         "note": "the gathered matrix (%.0f MB) is L2 / Infinity-Cache resident at this size: algorithmic "
-                                 "bytes (SURVEY 8d) are priced against the XCD-L2 peak (MI355X_MICROARCH.md: 34.5 TB/s; "
-                                 "measured ceiling for rows gathered from L2: 16.8-18.8 TB/s), HBM against the "
-                                 "compulsory bytes; the DRAM-bound regime is roofline_hbm" % (n_node * Fk * 4 / 1e6)},
             "mrr_hip": mrr,
             "mrr_hip_after_finetune": mrr_tuned,
             "metrics_hip": metrics,
@@ -606,11 +842,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             und_np = {"dst": und.edge_list[:, 1].cpu().numpy(), "src": und.edge_list[:, 0].cpu().numpy(),
                       "rel": und.edge_list[:, 2].cpu().numpy()}
-            result["cpu_baseline"] = cpu_baseline(und_np, n_node, R2, F)
-        if world == 1 and args.stress:
-            del xk, rk
-            torch.cuda.empty_cache()
-            result["roofline_hbm"] = stress_roofline(dev, lib)
+            result["cpu_baseline"] = cpu_baseline(und_np, n_node, R2, Fk)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

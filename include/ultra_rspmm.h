@@ -109,7 +109,9 @@ int ultra_rspmm_event_elapsed_ms(void *start_event, void *stop_event, float *ms_
  * them from staging a small gathered matrix in LDS, bit 2 selects one chunk per wave (packed_kernel) where four
  * chunks per wave (quad_kernel) would run, bit 3 the chunked kernels where one row per 16-lane group (rowgroup_kernel)
  * would run, bit 4 the wide-group forms of that kernel (32 / 64 lanes per row, column tiles of 128 / 256) on inputs small
- * enough to be cache-resident.  All paths return identical bits. */
+ * enough to be cache-resident, bit 5 makes quad_kernel walk a label's column tiles one after the other where it would
+ * work on several at once (small graphs).  Bit 0 also selects the L2-row form of the first-layer frontier kernel where the
+ * LDS-message form would run.  All paths return identical bits. */
 int ultra_rspmm_force_general_path(int on);
 
 /* Scratch bytes a call over `seg` with row width F needs (piece partial sums). */

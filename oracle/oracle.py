@@ -59,6 +59,7 @@ def native_forward_fn(threads=None):
                            "-fno-fast-math", "-fopenmp", "-shared", "-o", so, os.path.join(_HERE, "rspmm_oracle.c"), "-lm"])
     native = ctypes.CDLL(so)
     native.oracle_rspmm_forward.restype = ctypes.c_int
+    native.oracle_set_threads.restype = ctypes.c_int
 
     def forward(csr, relation, x, sum="add", mul="mul", piece=0):
         F = x.shape[1]
@@ -69,6 +70,7 @@ def native_forward_fn(threads=None):
         if rc:
             raise RuntimeError("oracle_rspmm_forward (native build) failed: %d" % rc)
         return out
+    forward.set_threads = lambda n: int(native.oracle_set_threads(int(n)))
     return forward
 
 

@@ -90,6 +90,18 @@ static inline float nary_identity(int sum_op) {
 
 int oracle_abi_version(void) { return 1; }
 
+/* OpenMP team size of the calls that follow (bench.py's cpu_baseline times a few team sizes: a GPU box's affinity mask
+ * may list more cores than its CPU share grants); returns the size in force. */
+int oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 /*
  * Forward.  row_ptr[N_rows+1], col/rel/w[E] are the coalesced CSR of the
  * (N_dst, N_src, R) adjacency the reference hands over at layer.py:127,328

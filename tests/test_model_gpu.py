@@ -385,49 +385,38 @@ def test_gradient_reducer_over_rccl_single_rank_group():
             assert torch.equal(a, b)
 
         # the fastest training mode, engine.GraphedTrainStep, WITH the reducer (it applied the warm-up's
-        # gradients on its first step; VERDICT r2: no overlap under replay).  The hooks fire inside the captured backward,
-        # so each bucket's collective is a branch of the captured graph on the reducer's side stream; every replay must
-        # leave the parameters of the same eager steps (the graph draws its own negatives: they are replayed eagerly).
-        task.load_state_dict(state)
-        twin = copy.deepcopy(task)
-        opt_g = torch.optim.AdamW(twin.parameters(), lr=1e-3)
-        reducer = engine.GradientReducer(twin, overlap=True, single_rank=True)
-        step = engine.GraphedTrainStep(twin, opt_g, batches[0], reducer=reducer)
-        losses_g, negs = [], []
-        for b in batches:
-            losses_g.append(step(b)[0].item())
-            negs.append(step.last_negatives.clone())
-        torch.cuda.synchronize()
-        opt_e = torch.optim.AdamW(task.parameters(), lr=1e-3)
-        losses_e = []
-        for b, neg in zip(batches, negs):
-            task._static_negative = neg
-            losses_e.append(engine.train_step(task, opt_e, b)[0].item())
-        task._static_negative = None
-        assert losses_g == losses_e
-        for (k, a), (_, b) in zip(task.named_parameters(), twin.named_parameters()):
-            assert torch.equal(a, b), k
-        # on this runtime the collectives are expected inside the graph; if the capture was refused the fallback
-        # (reduce after the replay) was taken with a warning and the numbers above still hold
-        print("GraphedTrainStep.reduce_in_graph =", step.reduce_in_graph)
-        if step.reduce_in_graph:
-            assert reducer.launched_from_hooks == len(reducer.buckets)          # all buckets started during the backward
-        reducer.remove_hooks()
-        # the same with the collectives kept outside the graph (the fallback path, forced)
-        task.load_state_dict(state)
-        twin2 = copy.deepcopy(task)
-        opt_2 = torch.optim.AdamW(twin2.parameters(), lr=1e-3)
-        reducer2 = engine.GradientReducer(twin2, overlap=True, single_rank=True)
-        step2 = engine.GraphedTrainStep(twin2, opt_2, batches[0], reducer=reducer2, reduce_in_graph=False)
-        assert not step2.reduce_in_graph
-        opt_e = torch.optim.AdamW(task.parameters(), lr=1e-3)
-        for b in batches:
-            step2(b)
-            task._static_negative = step2.last_negatives.clone()
-            engine.train_step(task, opt_e, b)
-        task._static_negative = None
-        for (k, a), (_, b) in zip(task.named_parameters(), twin2.named_parameters()):
-            assert torch.equal(a, b), k
-        reducer2.remove_hooks()
+        # gradients on its first step).  Default: the step is captured with the hooks paused and the buckets go out after
+        # each replay.  reduce_in_graph=True: hooks live inside the capture, the captured step verified against eager
+        # gradients before use -- whichever form ends up active, every replay must leave the parameters of the same eager
+        # steps (the graph draws its own negatives: they are replayed eagerly).
+        import warnings
+        for in_graph in (False, True):
+            twin = fresh_copy()
+            opt_g = torch.optim.AdamW(twin.parameters(), lr=1e-3)
+            reducer = engine.GradientReducer(twin, overlap=True, single_rank=True)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                step = engine.GraphedTrainStep(twin, opt_g, batches[0], reducer=reducer, reduce_in_graph=in_graph)
+            fell_back = any("reduced after each replay" in str(w.message) for w in caught)
+            print("GraphedTrainStep(reduce_in_graph=%s): active in graph = %s, fell back = %s" % (in_graph, step.reduce_in_graph, fell_back))
+            assert step.reduce_in_graph or not in_graph or fell_back       # never silently
+            assert not (step.reduce_in_graph and not in_graph)
+            losses_g, negs = [], []
+            for b in batches:
+                losses_g.append(step(b)[0].item())
+                negs.append(step.last_negatives.clone())
+            torch.cuda.synchronize()
+            opt_e = torch.optim.AdamW(task.parameters(), lr=1e-3)
+            losses_e = []
+            for b, neg in zip(batches, negs):
+                task._static_negative = neg
+                losses_e.append(engine.train_step(task, opt_e, b)[0].item())
+            task._static_negative = None
+            assert losses_g == losses_e, (in_graph, step.reduce_in_graph)
+            for (k, a), (_, b) in zip(task.named_parameters(), twin.named_parameters()):
+                assert torch.equal(a, b), (k, in_graph, step.reduce_in_graph)
+            if step.reduce_in_graph:
+                assert reducer.launched_from_hooks == len(reducer.buckets)      # all buckets started during the backward
+            reducer.remove_hooks()
     finally:
         dist.destroy_process_group()

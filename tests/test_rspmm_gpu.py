@@ -239,8 +239,11 @@ def test_sparse_tensor_entry_and_errors():
         UF.generalized_rspmm(adjacency, relation, x, mul="rotate")
     with pytest.raises(RuntimeError):
         UF.generalized_rspmm(adjacency, relation, x[:-1])
+    # CPU tensors go to the CPU kernels of the same dispatcher operator (sequential order per row): every row of this
+    # graph is unsplit, so the two devices agree bit for bit; mixing devices is an error
+    assert torch.equal(UF.generalized_rspmm(adjacency.cpu(), relation.cpu(), x.cpu()), out.cpu())
     with pytest.raises(RuntimeError):
-        UF.generalized_rspmm(adjacency.cpu(), relation.cpu(), x.cpu())      # no CPU fallback
+        UF.generalized_rspmm(adjacency, relation.cpu(), x.cpu())
     v = UF.generalized_rspmm(adjacency, relation[:, 0].contiguous(), x[:, 0].contiguous())   # 1-D input
     torch.testing.assert_close(v, dense[:, 0], rtol=1e-4, atol=1e-4)
 

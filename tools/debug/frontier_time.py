@@ -13,6 +13,7 @@ def main():
     from ultra_torchdrug_amd.graph import Graph
     from ultra_torchdrug_amd.task import build_ultra
     dev = torch.device("cuda:0")
+    U.require_library().ultra_rspmm_force_general_path(int(os.environ.get("ULTRA_KNOB", "0")))
     n_node, n_fact, n_rel = 14541, 272115, 237
     triples, _, _ = synthetic_triples((n_node, n_fact + 2048, n_rel), DEFAULT_SEED)
     mask = np.zeros(len(triples), dtype=bool); mask[:n_fact] = True

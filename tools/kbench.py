@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--piece", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--general", action="store_true")
+    ap.add_argument("--knob", type=int, default=0, help="ultra_rspmm_force_general_path bits (include/ultra_rspmm.h)")
     ap.add_argument("--backward", action="store_true")
     ap.add_argument("--boundary", action="store_true", help="forward with the fused `+ boundary` epilogue (add_rows), as inside a layer")
     ap.add_argument("--relgraph", action="store_true", help="the workload's RELATION graph (2R nodes, 4 edge types) instead of the entity graph")
@@ -32,7 +33,7 @@ def main():
     from ultra_torchdrug_amd import _lib, relcsr, functional as UF
     from ultra_torchdrug_amd.data import synthetic_kg
     lib = U.require_library()
-    lib.ultra_rspmm_force_general_path(1 if args.general else 0)
+    lib.ultra_rspmm_force_general_path((1 if args.general else 0) | args.knob)
     dev = torch.device("cuda:0")
     g = synthetic_kg(args.workload, device=dev)
     if args.relgraph:

@@ -330,6 +330,7 @@ struct PParams {
     int split;
     int n_slots;
     int blocks_per_label;
+    int concurrent;          // quad_kernel: teams per label working on different column tiles at once (0 / 1: none)
 };
 
 // VAR 0: node id inside the packed word, relation tile in LDS (KG-sized graphs).
@@ -1132,6 +1133,9 @@ int launch_rowgroup(RowGroupParams &q, bool backward, int sum_op, int mul_op, bo
 }
 
 bool g_no_rowgroup = false;
+bool g_no_concurrent_tiles = false;
+constexpr unsigned long long kConcurrentSliceBytes = 2560ull * 1024;      // slices of concurrently processed tiles per XCD
+constexpr bool TWO_GATHERS_KIND(int kind) { return kind == KIND_DREL; }
 
 // Runs one plan: segment_kernel over the chunk schedule, then fixup_kernel over the split rows.
 template <int KIND>
@@ -1291,7 +1295,20 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
                               (KIND != KIND_DREL || gather2_rows < (1ll << 24)) && aligned16(gather) && aligned16(p.grad) &&
                               aligned16(p.out) && aligned16(p.add_rows) && aligned16(p.partial) && aligned16(p.bvec) &&
                               (p.bnode == nullptr || p.bdim % 4 == 0);
-            if (quad) rc = launch_quad<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var == 1, grid, kLdsHeader + lds_bytes, stream);
+            if (quad) {
+                // tiles of one label side by side (quad.inc): as many as the label has, while every team keeps >= 4
+                // workgroups and the tiles' slices of the gathered matrix (LDS-resident with var 1) fit the XCD's 4 MB L2
+                // together with the streams around them
+                const int slots_per_label = (q.n_slots + kXcd - 1) / kXcd;
+                const unsigned long long slice = (var == 1) ? 0ull : (unsigned long long)gather_rows * kTile * 4ull +
+                                                                     (TWO_GATHERS_KIND(KIND) ? (unsigned long long)gather2_rows * kTile * 4ull : 0ull);
+                int conc = 1;
+                while (!g_no_concurrent_tiles && conc * 2 <= slots_per_label && blocks_per_label % (conc * 2) == 0 &&
+                       blocks_per_label / (conc * 2) >= 4 && (unsigned long long)(conc * 2) * slice <= kConcurrentSliceBytes)
+                    conc *= 2;
+                q.concurrent = conc;
+                rc = launch_quad<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var == 1, grid, kLdsHeader + lds_bytes, stream);
+            }
             if (!quad) rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var, grid, kLdsHeader + lds_bytes, stream);
             if (rc) return rc;
         }
@@ -1366,6 +1383,7 @@ int ultra_rspmm_force_general_path(int on) {
     g_no_quad = (on & 4) != 0;            // bit 2: one chunk per wave (packed_kernel) instead of four (quad_kernel)
     g_no_rowgroup = (on & 8) != 0;        // bit 3: chunked kernels where one row per group (rowgroup_kernel) would run
     g_wide_groups = (on & 16) != 0;       // bit 4: rowgroup_kernel with 32 / 64 lanes per row even for cache-sized inputs
+    g_no_concurrent_tiles = (on & 32) != 0;   // bit 5: quad_kernel walks a label's column tiles one after the other
     return ULTRA_OK;
 }
 
@@ -1512,11 +1530,26 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
     p.piece_len = (int)by_src->piece_len;
     // 64 workgroups x 16 groups per query: a hub head with tens of thousands of out-edges still leaves every group a
     // few dozen (the groups of a low-degree query find an empty slice and exit)
-    p.slices = 64;
-    const dim3 grid((unsigned)(F / 64), (unsigned)p.slices);
-    if (by_src->weight == nullptr) hipLaunchKernelGGL(frontier_kernel<true>, grid, dim3(kFrontierThreads), 0, s, p);
-    else hipLaunchKernelGGL(frontier_kernel<false>, grid, dim3(kFrontierThreads), 0, s, p);
-    HIP_TRY(hipGetLastError());
+    p.n_rel = (int)n_rel;
+    p.piece_shift = -1;
+    for (int sh = 0; sh < 31; ++sh)
+        if ((1LL << sh) == by_src->piece_len) p.piece_shift = sh;
+    const size_t msg_bytes = (size_t)n_rel * kTile * sizeof(float);
+    if (!g_force_general && n_rel > 0 && msg_bytes <= (size_t)kMaxLdsBytes) {
+        // the query's R messages in LDS, ids 16 at a time (frontier_lds_kernel): one workgroup of 64 groups per slice
+        p.slices = kFrontierLdsSlices;
+        const int grid = (int)(F / 64) * p.slices;
+        int rc = by_src->weight == nullptr
+                     ? launch_with_lds(frontier_lds_kernel<true>, p, grid, msg_bytes, s, kFrontierLdsThreads)
+                     : launch_with_lds(frontier_lds_kernel<false>, p, grid, msg_bytes, s, kFrontierLdsThreads);
+        if (rc) return rc;
+    } else {
+        p.slices = 64;
+        const dim3 grid((unsigned)(F / 64), (unsigned)p.slices);
+        if (by_src->weight == nullptr) hipLaunchKernelGGL(frontier_kernel<true>, grid, dim3(kFrontierThreads), 0, s, p);
+        else hipLaunchKernelGGL(frontier_kernel<false>, grid, dim3(kFrontierThreads), 0, s, p);
+        HIP_TRY(hipGetLastError());
+    }
     if (ev_stop != nullptr) HIP_TRY(hipEventRecord(ev_stop, s));
     return ULTRA_OK;
 }

@@ -124,25 +124,29 @@ class GraphedPredict:
 
 class GraphedTrainStep:
     """One fine-tuning step (``ultra/engine.py:62-92``) for a fixed batch size as ONE hipGraph: strict negative
-    sampling, removal of the batch's own edges, forward, backward -- and, with a :class:`GradientReducer`, the bucketed
-    gradient all-reduce.  A step is ~800 launches, most of them tiny, and their host-side issue cost exceeds the GPU time
-    of the kernels.  Nothing in the step has a data-dependent shape any more: the negatives come from the sorted
-    completion keys (``ultra_strict_negative``) and the edge removal from a binary search in the plans
-    (``ultra_edge_removal_weights``), where the reference builds ``(B / 2, N)`` masks, calls ``nonzero`` and re-sorts a new
-    graph (task.py:102-118, model.py:57-74).
+    sampling, removal of the batch's own edges, forward, backward.  A step is ~800 launches, most of them tiny, and
+    their host-side issue cost exceeds the GPU time of the kernels.  Nothing in the step has a data-dependent shape any
+    more: the negatives come from the sorted completion keys (``ultra_strict_negative``) and the edge removal from a
+    binary search in the plans (``ultra_edge_removal_weights``), where the reference builds ``(B / 2, N)`` masks, calls
+    ``nonzero`` and re-sorts a new graph (task.py:102-118, model.py:57-74).  The optimizer step follows the replay
+    eagerly.  Models the native removal does not cover (min / max / PNA aggregation, ``remove_one_hop``) keep eager
+    steps: use :func:`train_step`.
 
-    Overlap under replay (BASELINE north star: "all-reduce ... overlapped with the next layer's rspmm on a side HIP
-    stream").  The reducer's ``post_accumulate_grad`` hooks fire DURING the captured backward: each bucket's pack lands
-    on the capturing stream, its RCCL all-reduce on the reducer's side stream (forked from the capturing stream by an
-    event wait, so it becomes a parallel branch of the captured graph), and ``reducer.finish()`` -- also captured --
-    joins the branch and unpacks.  A replay therefore runs the same fork / collective / join structure as an eager
-    ``train_step``: the collective nodes depend only on their bucket's pack, not on the rspmm backward kernels of the
-    layers that follow.  ``reduce_in_graph`` tells whether that capture succeeded; if the runtime refuses to capture
-    the collectives, the step is captured without them and the same buckets go out right after each replay (no
-    overlap, same numbers).  The optimizer step follows the replay eagerly.  Models the native removal does not cover
-    (min / max / PNA aggregation, ``remove_one_hop``) keep eager steps: use :func:`train_step`."""
+    With a :class:`GradientReducer` the gradient all-reduce goes one of two ways:
 
-    def __init__(self, task, optimizer, example_batch, warmup=3, reducer=None, reduce_in_graph=True):
+    * default -- the step is captured with the reducer's hooks paused and the buckets go out right after each replay
+      (``reducer.reduce_all()``: bucket order, side stream), i.e. communication FOLLOWS the replayed backward;
+    * ``reduce_in_graph=True`` -- the hooks stay live during the capture, so every bucket's pack and RCCL all-reduce become
+      nodes of the graph on the reducer's side stream, dependent on that layer's gradients only (the overlap of an eager
+      ``train_step`` with hooks, under replay), and ``finish()`` is captured too.  The captured step is then VERIFIED
+      before it is used: two replays against eager backward passes on the same batch and negatives; any difference
+      drops back to the default with a warning.  On the runtime this was developed on (PyTorch 2.10 + ROCm 7.0, RCCL
+      2.26, one-rank group) the verification fails -- a captured all-reduce alone replays correctly, the captured step
+      with bucket traffic does not (``tools/debug/graph_collective_probe.py``, ``graphed_reducer_diag2.py``; DESIGN.md
+      section 6) -- so the flag is opt-in and the overlap under replay remains unproven there.
+    ``reduce_in_graph`` (attribute) tells which form is active."""
+
+    def __init__(self, task, optimizer, example_batch, warmup=3, reducer=None, reduce_in_graph=False):
         assert example_batch.is_cuda and task.training
         model = task.model
         if model.remove_one_hop or not model._removal_by_zero_weight(sums_only=True):
@@ -163,15 +167,18 @@ class GraphedTrainStep:
                     if reducer is not None:         # whole steps: the hooks' collectives are waited for and unpacked, so
                         reducer.finish()            # no bucket state survives into the capture (and RCCL is warm)
             torch.cuda.current_stream().wait_stream(side)
-            in_graph = reducer is not None and reduce_in_graph and reducer.overlap and reducer._active()
-            if in_graph:
+            if reducer is not None and reduce_in_graph and reducer.overlap and reducer._active():
+                import warnings
                 try:
                     self._capture(reduce=True)
-                    self.reduce_in_graph = True
-                except Exception as err:            # the runtime refused collective nodes: capture the step without them
-                    import warnings
+                    self.reduce_in_graph = self._verify_captured_reduction()
+                    if not self.reduce_in_graph:
+                        warnings.warn("GraphedTrainStep: the step captured WITH the gradient all-reduce does not reproduce "
+                                      "eager gradients on this runtime; the buckets are reduced after each replay instead")
+                except Exception as err:            # the runtime refused collective nodes
                     warnings.warn("GraphedTrainStep: capturing the gradient all-reduce failed (%s); the buckets are "
                                   "reduced after each replay instead" % (str(err).splitlines()[0] if str(err) else type(err).__name__))
+                if not self.reduce_in_graph:
                     torch.cuda.synchronize()
                     reducer.abandon()
             if not self.reduce_in_graph:
@@ -191,6 +198,39 @@ class GraphedTrainStep:
             self.static_loss.backward()
             if reduce:
                 self.reducer.finish()
+
+    def _verify_captured_reduction(self, rounds=2):
+        """Replays of the step captured with the bucket traffic against eager backward passes on the same batch and the
+        negatives each replay drew (one-rank group: EQUAL; more ranks: all ranks hold the same example batch here, so
+        the mean over ranks is that gradient again, up to the rounding of sum / world)."""
+        task, world = self.task, get_world_size()
+        params = [p for p in task.parameters() if p.grad is not None]
+        ok = True
+        for _ in range(rounds):
+            self.graph.replay()
+            torch.cuda.synchronize()
+            captured = [p.grad for p in params]
+            got = [g.clone() for g in captured]
+            for p in params:
+                p.grad = None
+            task._static_negative = task.last_negatives.clone()
+            try:
+                with self.reducer.paused():
+                    loss, _ = task(self.static_batch)
+                    loss.backward()
+            finally:
+                task._static_negative = None
+            torch.cuda.synchronize()
+            for p, g, keep in zip(params, got, captured):
+                want = p.grad
+                same = want is not None and (torch.equal(g, want) if world == 1 else
+                                             bool(((g - want).abs() <= 1e-6 * want.abs().max() + 1e-12).all()))
+                ok = ok and same
+                p.grad = keep
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.static_batch.device)
+        if world > 1:                               # every rank takes the same branch
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
 
     def __call__(self, batch):
         """One step on ``batch`` (same shape as the example): returns ``(loss, metrics averaged over ranks)``."""
@@ -516,14 +556,9 @@ class GradientReducer:
         flat = bucket["flat"]
         if flat is None or flat.device != ref.device:
             flat = bucket["flat"] = torch.empty(bucket["numel"], dtype=torch.float32, device=ref.device)
-        offset = 0
-        for p in params:                                                     # packed on the compute stream
-            n = p.numel()
-            if p.grad is not None:
-                flat[offset:offset + n].copy_(p.grad.reshape(-1))
-            else:
-                flat[offset:offset + n].zero_()
-            offset += n
+        # packed on the compute stream by ONE kernel (cat; copy_() of same-dtype tensors would be a device-to-device
+        # memcpy, i.e. a memcpy NODE under hipGraph capture: kernels only, see DESIGN.md on memset nodes)
+        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params], out=flat)
         if flat.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=flat.device)
@@ -556,8 +591,8 @@ class GradientReducer:
                 n = p.numel()
                 if p.grad is None:
                     p.grad = flat[offset:offset + n].view_as(p).clone()
-                else:
-                    p.grad.copy_(flat[offset:offset + n].view_as(p.grad))
+                else:                                                       # an elementwise kernel, not a memcpy (see _launch)
+                    torch.mul(flat[offset:offset + n].view_as(p.grad), 1.0, out=p.grad)
                 offset += n
             total += flat.numel()
             bucket["work"] = None
