@@ -384,6 +384,16 @@ def test_gradient_reducer_over_rccl_single_rank_group():
         for a, b in zip(finals["plain"], finals["reducer"]):
             assert torch.equal(a, b)
 
+        def fresh_copy():
+            """A second task on the same seeded graph at the initial weights (a deepcopy of `task` would have to copy the
+            per-call tensors its last step left on modules and graphs, which are not leaves)."""
+            other, _ = _build("S-tiny")
+            other.num_negative = 16
+            other.to(dev).train()
+            other.load_state_dict(state)
+            task.load_state_dict(state)
+            return other
+
         # the fastest training mode, engine.GraphedTrainStep, WITH the reducer (ADVICE r2: it applied the warm-up's
         # gradients on its first step).  Default: the step is captured with the hooks paused and the buckets go out after
         # each replay.  reduce_in_graph=True: hooks live inside the capture, the captured step verified against eager

@@ -1,0 +1,63 @@
+#!/bin/bash
+# Regenerates the judged profile artefacts of a round on the GPU box, under gpurun_out/<tag>/ (copy into profiles/):
+#   <tag>_bench_under_rocprof.json      bench.py's JSON line, run under rocprofv3 --kernel-trace --stats
+#   <tag>_bench_kernel_stats.csv        rocprofv3's per-kernel summary of that command
+#   <tag>_bench_dominant_kernel.json    the library's kernels out of it (launches, average us, share)
+#   <tag>_traffic_stress.json           S-stress rowgroup kernel: HBM bytes per launch from separate --pmc passes
+#   <tag>_traffic_fwd_fb15k237.json     headline graph's forward kernel (F = 2048): the same
+#   <tag>_stress_rowgroup_pmc.txt / <tag>_kbench_fwd_pmc.txt   the counter means those come from
+# usage (gpurun): bash tools/profile_round.sh r03
+tag=${1:-r03}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+PY=$(readlink -f "$(command -v python3)")     # the ELF interpreter itself: no shim may exec after the profiler's preload
+if ! head -c 4 "$PY" | grep -q ELF; then echo "python3 resolves to $PY, which is not an ELF binary" >&2; exit 1; fi
+out=gpurun_out/$tag
+rm -rf "$out"; mkdir -p "$out"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/bench" -o bench -- "$PY" bench.py --steps 200 --warmup 20 > "$out/bench_under_rocprof.log" 2>&1
+grep "^{\"metric\"" "$out/bench_under_rocprof.log" | tail -1 > "$out/${tag}_bench_under_rocprof.json"
+find "$out/bench" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_bench_kernel_stats.csv" \;
+rm -rf "$out/bench"
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  rocprofv3 --pmc $pass --output-format csv -d "$out/stress_$name" -- "$PY" tools/stress_bench.py --reps 2 --knob 0 > "$out/stress_$name.log" 2>&1
+  rocprofv3 --pmc $pass --output-format csv -d "$out/fwd_$name" -- "$PY" tools/kbench.py --workload S-fb15k237 --batch 32 --reps 4 > "$out/fwd_$name.log" 2>&1
+done
+"$PY" - "$out" "$tag" <<'PY'
+import csv, glob, json, sys
+from collections import defaultdict
+out, tag = sys.argv[1], sys.argv[2]
+rows = list(csv.DictReader(open("%s/%s_bench_kernel_stats.csv" % (out, tag))))
+ours = {r["Name"]: {"launches": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "percent": float(r["Percentage"])}
+        for r in rows if "anonymous namespace" in r["Name"] and "at::native" not in r["Name"]}
+json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 20",
+           "kernels": ours}, open("%s/%s_bench_dominant_kernel.json" % (out, tag), "w"), indent=1)
+
+
+def means(prefix, pattern):
+    vals = defaultdict(list)
+    for f in sorted(glob.glob("%s/%s_*/**/*_counter_collection.csv" % (out, prefix), recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if pattern in r["Kernel_Name"]:
+                vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v[-2:]) / len(v[-2:]) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
+
+
+for prefix, pattern, name, algo, cmd, txt in (
+        ("stress", "rowgroup_kernel", "traffic_stress", 29400256004, "python3 tools/stress_bench.py --reps 2 --knob 0", "stress_rowgroup_pmc"),
+        ("fwd", "quad_kernel", "traffic_fwd_fb15k237", 4587923968, "python3 tools/kbench.py --workload S-fb15k237 --batch 32 --reps 4", "kbench_fwd_pmc")):
+    m, n = means(prefix, pattern)
+    with open("%s/%s_%s.txt" % (out, tag, txt), "w") as f:
+        f.write("# rocprofv3 --pmc <one counter set per pass> -- %s ; mean of the last 2 dispatches of *%s*\n" % (cmd, pattern))
+        for k in sorted(m):
+            f.write("%-28s %18.1f  (dispatches seen: %d)\n" % (k, m[k], n[k]))
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        hbm = int(2 * m["FETCH_SIZE"] * 1024 + m["WRITE_SIZE"] * 1024)
+        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) -- %s; kernel *%s*" % (cmd, pattern),
+                   "FETCH_SIZE_KB_per_launch": m["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": m["WRITE_SIZE"],
+                   "TCC_HIT_sum": m.get("TCC_HIT_sum"), "TCC_MISS_sum": m.get("TCC_MISS_sum"),
+                   "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
+                   "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo, "F": 64 if prefix == "stress" else 2048},
+                  open("%s/%s_%s.json" % (out, tag, name), "w"), indent=1)
+PY
+rm -rf "$out"/stress_* "$out"/fwd_*
+ls -la "$out"
