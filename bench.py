@@ -533,11 +533,11 @@ def main():
     real_forward = UF.rspmm_forward
     state = {"on": False}
 
-    def timed_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, boundary=None, **kw):
+    def timed_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, boundary=None):
         if state["on"] and csr is und.relcsr:
             a, b = events.new_pair()
             lib.ultra_rspmm_profile_next(a, b)
-        return real_forward(csr, relation, input, sum, mul, add_rows, boundary, **kw)
+        return real_forward(csr, relation, input, sum, mul, add_rows, boundary)
 
     UF.rspmm_forward = timed_forward
 

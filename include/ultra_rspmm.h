@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_RSPMM_ABI_VERSION 4
+#define ULTRA_RSPMM_ABI_VERSION 3
 
 /* sum= / mul= of generalized_rspmm (layer.py:134-167: sum in {"add","max","min"}, mul in {"mul","add"}) */
 enum ultra_sum_op { ULTRA_SUM_ADD = 0, ULTRA_SUM_MIN = 1, ULTRA_SUM_MAX = 2 };
@@ -156,17 +156,6 @@ int ultra_rspmm_forward_boundary_f32(const ultra_segments *fwd, const float *rel
                                      void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_rel, int64_t F,
                                      int sum_op, int mul_op, void *stream);
 
-/* The same forward (sum aggregation) WITHOUT the pass that adds the pieces of split rows: the piece sums stay in
- * `workspace` and the rows of `out` that the plan splits (fwd->long_rows) are left unwritten.  For callers whose next
- * kernel reads `out` once anyway and can add the pieces itself -- ultra_combine_forward_deferred_f32 below: one launch
- * and one write + read of those rows less per layer.  The boundary (dense `add_rows`, or sparse node / value / block as
- * above, or neither) is then NOT applied to the split rows either: hand the same boundary to the consumer.  Unsplit
- * rows are complete, boundary included. */
-int ultra_rspmm_forward_deferred_f32(const ultra_segments *fwd, const float *relation, const float *input,
-                                     const float *add_rows, const int32_t *boundary_node, const float *boundary_value,
-                                     int64_t block, float *out, void *workspace, size_t workspace_bytes, int64_t n_src,
-                                     int64_t n_rel, int64_t F, int mul_op, void *stream);
-
 /* The FIRST Bellman-Ford layer: `input` IS the boundary (ultra/model.py:116-120, ultra/rel_model.py:365-369), zero outside
  * row boundary_node[b] of query block b.  For sum = add, mul = mul (DistMult messages, summed: the shipped configuration)
  * every edge whose source row is zero contributes w * (rel * 0) = +-0 and can be skipped without changing one bit of the
@@ -229,21 +218,6 @@ int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd_host, const float 
 int ultra_combine_forward_f32(const float *input, const float *update, const float *weight, const float *bias,
                               const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
                               float *out, int64_t rows, int64_t dim, void *stream);
-
-/* The same epilogue on an `update` that came from ultra_rspmm_forward_deferred_f32: rows = n_nodes * (F / 64), row
- * (v, q) = columns [64 q, 64 q + 64) of node v.  For a node the plan splits (long_index[v] = i >= 0: long_rows[i] =
- * {v, first piece, number of pieces}) the epilogue's `update` operand is
- *     ((0 + piece[first]) + piece[first + 1]) + ...  (+ boundary of that row)
- * taken from `partial` ([n_pieces, F], the rspmm call's workspace) in piece order -- what the fix-up pass would have
- * written to `update` and this kernel would have read back: identical bits.  long_index: int32 [n_nodes], -1 for unsplit
- * nodes.  F % 256 == 0 (a 4-row load never straddles two nodes).  Boundary: dense add_rows [n_nodes, F], or sparse
- * (boundary_node int32 [F / block], boundary_value fp32 [F]), or neither. */
-int ultra_combine_forward_deferred_f32(const float *input, const float *update, const float *weight, const float *bias,
-                                       const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                                       float *out, int64_t rows, int64_t dim, const int32_t *long_index,
-                                       const int32_t *long_rows, const float *partial, int64_t F, const float *add_rows,
-                                       const int32_t *boundary_node, const float *boundary_value, int64_t block,
-                                       void *stream);
 
 
 /*

@@ -52,10 +52,9 @@ class OracleFunctional:
         return not tensor.is_cuda
 
     def combine(self, input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,
-                reuse_update=False, deferred=None):
+                reuse_update=False):
         """Layer epilogue on the CPU: the oracle's C restatement (the HIP kernel's documented order) for inference,
         the reference's own torch chain (layer.py:386-392, model.py:126-127) when autograd is needed."""
-        assert deferred is None                       # the oracle path never defers a fix-up (it has no pieces to add)
         tensors = [t for t in (input, update, weight, bias, ln_weight, ln_bias) if t is not None]
         if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
             out = torch.nn.functional.linear(torch.cat([input, update], dim=-1), weight, bias)

@@ -570,81 +570,3 @@ def test_hot_row_cache_variant_matches_plain_variant(oracle):
         da, ra = UF.rspmm_backward(hot, t(relation), t(x), None, t(grad), "add", m)
         db, rb = UF.rspmm_backward(cold, t(relation), t(x), None, t(grad), "add", m)
         assert torch.equal(da, db) and torch.equal(ra, rb)
-
-
-@pytest.mark.parametrize("boundary_form", ["sparse", "dense", "none"])
-@pytest.mark.parametrize("batch", [4, 16])
-def test_deferred_fixup_in_the_epilogue_equals_the_separate_pass(boundary_form, batch):
-    """rspmm_forward(defer_fixup=True) leaves the split rows to combine_forward(deferred=...): the epilogue kernel adds the
-    piece sums (and the boundary of those rows) itself.  The layer output must be EQUAL to fix-up pass + epilogue, hub
-    rows of many pieces, rows of exactly piece_len edges and the boundary rows of split nodes included; unsplit rows of
-    the intermediate `update` are equal too (the split ones are unwritten)."""
-    from ultra_torchdrug_amd import RelCSR, functional as UF
-    dev = _dev()
-    n, r = 700, 11
-    F = 64 * batch
-    g = random_graph(seed=21, n_node=n, n_edge=30000, n_rel=r, skew=True, hub_row=5, hub_edges=6000)
-    t = lambda a: torch.from_numpy(a).to(dev)
-    csr = RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), None, n, n, r, chunk_edges=16, piece_len=64)
-    assert csr.fwd.n_pieces > 50 and UF.deferral_supported(csr, F)
-    gen = torch.Generator(device=dev).manual_seed(batch)
-    relation = torch.randn(r, F, device=dev, generator=gen)
-    x = torch.randn(n, batch, 64, device=dev, generator=gen)
-    lin, norm = torch.nn.Linear(128, 64).to(dev), torch.nn.LayerNorm(64).to(dev)
-    split_nodes = csr.fwd.long_rows[:, 0].long()
-    node = torch.cat([split_nodes[:2], torch.randint(0, n, (batch - 2,), device=dev, generator=gen)]).to(torch.int32)
-    value = torch.randn(batch, 64, device=dev, generator=gen)
-    kw = {}
-    if boundary_form == "sparse":
-        kw = dict(boundary=(node, value))
-    elif boundary_form == "dense":
-        dense = torch.zeros(n, batch, 64, device=dev)
-        dense[node.long(), torch.arange(batch, device=dev)] = value
-        dense += 0.125 * torch.randn(n, batch, 64, device=dev, generator=gen)       # a boundary on every row
-        kw = dict(add_rows=dense.flatten(1))
-    with torch.no_grad():
-        update = UF.rspmm_forward(csr, relation, x.flatten(1), "add", "mul", **kw)
-        want = UF.combine_forward(x, update.view(n, batch, 64), lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, True)
-        partial, deferred = UF.rspmm_forward(csr, relation, x.flatten(1), "add", "mul", defer_fixup=True, **kw)
-        unsplit = torch.ones(n, dtype=torch.bool, device=dev)
-        unsplit[split_nodes] = False
-        assert torch.equal(partial[unsplit], update[unsplit])
-        got = UF.combine_forward(x, partial.view(n, batch, 64), lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, True,
-                                 deferred=deferred)
-        assert torch.equal(got, want)
-        # in place over `update` (what the layers do) and without LayerNorm / shortcut
-        partial, deferred = UF.rspmm_forward(csr, relation, x.flatten(1), "add", "mul", defer_fixup=True, **kw)
-        got2 = UF.combine_forward(x, partial.view(n, batch, 64), lin.weight, lin.bias, None, None, 1e-5, False, False,
-                                  reuse_update=True, deferred=deferred)
-        want2 = UF.combine_forward(x, update.view(n, batch, 64), lin.weight, lin.bias, None, None, 1e-5, False, False)
-        assert torch.equal(got2, want2)
-    with pytest.raises(RuntimeError):
-        UF.rspmm_forward(csr, relation[:, :64].contiguous(), x[:, 0].contiguous(), "add", "mul", defer_fixup=True)   # F = 64
-
-
-def test_layers_defer_the_fixup_and_predict_is_unchanged():
-    """The inference layers use the deferred fix-up by default; switching it off gives identical scores."""
-    from ultra_torchdrug_amd import functional as UF
-    from ultra_torchdrug_amd.data import synthetic_triples
-    from ultra_torchdrug_amd.graph import Graph
-    from ultra_torchdrug_amd.task import build_ultra
-    triples, n, r = synthetic_triples((1200, 9000, 12), 1024)
-    torch.manual_seed(1024)
-    task = build_ultra(r)
-    task.preprocess(Graph(torch.from_numpy(triples), num_node=n, num_relation=r))
-    task.to(_dev()).eval()
-    batch = torch.from_numpy(triples[:16]).to(_dev())
-    calls = []
-    real = UF.combine_forward
-    UF.combine_forward = lambda *a, **k: (calls.append(k.get("deferred") is not None), real(*a, **k))[1]
-    try:
-        with torch.no_grad():
-            with_defer = task.predict(batch)
-            n_deferred = sum(calls)
-            UF.DEFER_FIXUP = False
-            without = task.predict(batch)
-    finally:
-        UF.DEFER_FIXUP = True
-        UF.combine_forward = real
-    assert n_deferred >= 5 and sum(calls) == n_deferred          # layers 2..6 of the entity stack (the first is the frontier)
-    assert torch.equal(with_defer, without)

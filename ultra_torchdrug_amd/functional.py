@@ -27,9 +27,6 @@ __all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
 _sparse_cache = collections.OrderedDict()
 _SPARSE_CACHE_ENTRIES = 4
-# Inference layers hand the fix-up of split rows to the epilogue kernel (rspmm_forward(defer_fixup=True) ->
-# combine_forward(deferred=...)); the switch exists for A/B timing and for the equality test.
-DEFER_FIXUP = True
 
 
 def accepts(tensor):
@@ -97,22 +94,11 @@ def _workspace(seg, F, device):
     return ws, n * 4
 
 
-def deferral_supported(csr, F, sum="add"):
-    """A forward whose split rows can be finished by the NEXT kernel (``combine_forward(deferred=...)``) instead of by a
-    fix-up launch of its own: summed messages, split rows present, 64-column query blocks in groups of four."""
-    return sum == "add" and F % 256 == 0 and csr.fwd.n_pieces > 0
-
-
-def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, boundary=None, defer_fixup=False):
+def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, boundary=None):
     """Forward only, no autograd.  ``add_rows`` fuses the boundary epilogue of ``layer.py:156,162,358,364``;
     ``boundary = (node, value)`` is the same epilogue with the boundary in its sparse form: ``node`` int32 ``(B,)``,
     ``value`` fp32 ``(B, D)`` with ``B * D == F`` -- row ``node[b]`` of query block ``b`` holds ``value[b]``, all else 0
-    (what ``scatter_add_`` builds in ``model.py:106-107``).
-
-    ``defer_fixup`` (only where :func:`deferral_supported`): returns ``(out, deferred)`` -- the rows of ``out`` that the
-    plan splits are left UNWRITTEN and their piece sums stay in the workspace ``deferred`` carries; hand ``deferred`` to
-    :func:`combine_forward`, which adds the pieces (and the boundary of those rows) while it reads ``out`` anyway: one
-    launch and one write + read of the split rows less per layer, identical bits."""
+    (what ``scatter_add_`` builds in ``model.py:106-107``)."""
     sum_op, mul_op = _ops(sum, mul)
     _check_dense(csr, relation, input)
     relation, input = relation.contiguous(), input.contiguous()
@@ -131,20 +117,6 @@ def rspmm_forward(csr, relation, input, sum="add", mul="mul", add_rows=None, bou
                 or b_value.shape[0] != b_node.shape[0] or b_value.numel() != F or b_node.device != out.device
                 or b_value.device != out.device or not b_node.is_contiguous()):
             raise RuntimeError("boundary must be (int32 (B,), fp32 (B, D)) with B * D == %d on %s" % (F, out.device))
-    if defer_fixup:
-        if not deferral_supported(csr, F, sum):
-            raise RuntimeError("rspmm_forward(defer_fixup=True): summed messages, F % 256 == 0 and a plan with split rows")
-        seg = csr.fwd
-        lib = _lib.load()
-        ws, ws_bytes = _workspace(seg, F, input.device)
-        b_node_, b_value_ = (boundary[0], b_value) if boundary is not None else (None, None)
-        with torch.cuda.device(input.device):
-            _lib.check(lib.ultra_rspmm_forward_deferred_f32(
-                seg.pointer, relation.data_ptr(), input.data_ptr(), add_rows.data_ptr() if add_rows is not None else None,
-                b_node_.data_ptr() if b_node_ is not None else None, b_value_.data_ptr() if b_value_ is not None else None,
-                b_value_.shape[1] if b_value_ is not None else 0, out.data_ptr(), ws.data_ptr(), ws_bytes, csr.shape[1],
-                csr.shape[2], F, _lib.MUL_OPS[mul], _stream()))
-        return out, {"segments": seg, "workspace": ws, "F": F, "add_rows": add_rows, "b_node": b_node_, "b_value": b_value_}
     if out.numel() == 0:
         return out
     seg = csr.fwd
@@ -292,7 +264,7 @@ def rspmm_backward_weight(csr, relation, input, output, output_grad, sum="add", 
 
 
 def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,
-                    reuse_update=False, deferred=None):
+                    reuse_update=False):
     """Fused ``combine`` (+ shortcut) of one layer, forward only: ``[input +] relu(LN(Linear(cat[input, update])))``
     (``ultra/layer.py:386-392``, ``ultra/model.py:126-127``).  ``input`` / ``update``: ``(..., 64)`` fp32 on the GPU.
     ``reuse_update``: the caller owns ``update`` and does not need it afterwards -- the result is written over it
@@ -308,22 +280,6 @@ def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, l
     out = update if reuse_update else torch.empty_like(input)
     rows = input.numel() // 64
     lib = _lib.load()
-    if deferred is not None:
-        # `update` came from rspmm_forward(defer_fixup=True): the kernel sums the pieces of split rows itself
-        seg, F = deferred["segments"], deferred["F"]
-        if rows != seg.n_rows * (F // 64):
-            raise RuntimeError("combine_forward(deferred=...): update must be the (n_rows, F) output of that rspmm call")
-        add_rows, b_node, b_value = deferred["add_rows"], deferred["b_node"], deferred["b_value"]
-        with torch.cuda.device(input.device):
-            _lib.check(lib.ultra_combine_forward_deferred_f32(
-                input.data_ptr(), update.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
-                ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
-                ln_bias.contiguous().data_ptr() if ln_weight is not None else None,
-                float(ln_eps), int(bool(relu)), int(bool(shortcut)), out.data_ptr(), rows, 64, seg.long_index.data_ptr(),
-                seg.long_rows.data_ptr(), deferred["workspace"].data_ptr(), F,
-                add_rows.data_ptr() if add_rows is not None else None, b_node.data_ptr() if b_node is not None else None,
-                b_value.data_ptr() if b_value is not None else None, b_value.shape[1] if b_value is not None else 0, _stream()))
-        return out
     with torch.cuda.device(input.device):
         _lib.check(lib.ultra_combine_forward_f32(
             input.data_ptr(), update.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
@@ -642,17 +598,15 @@ class _CombineFunction(torch.autograd.Function):
 
 
 def combine(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,
-            reuse_update=False, deferred=None):
+            reuse_update=False):
     """``combine`` + shortcut of one layer (``ultra/layer.py:386-392``, ``ultra/model.py:126-127``) as fused HIP
     kernels, differentiable: same forward as :func:`combine_forward`, fused backward.  ``reuse_update`` (inference
     only): see :func:`combine_forward`."""
     tensors = [t for t in (input, update, weight, bias, ln_weight, ln_bias) if t is not None]
     if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-        if deferred is not None:
-            raise RuntimeError("combine(deferred=...) is an inference path (the training layer is sum_layer)")
         return _CombineFunction.apply(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
     return combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut,
-                           reuse_update=reuse_update and update.is_contiguous(), deferred=deferred)
+                           reuse_update=reuse_update and update.is_contiguous())
 
 
 class _RSPMMFunction(torch.autograd.Function):
@@ -709,7 +663,6 @@ class _SumLayerFunction(torch.autograd.Function):
         shape = input.shape                                      # (N, B, 64)
         flat = input.flatten(1)
         boundary = None if b_node is None else (b_node, b_value.detach())
-        # (no deferred fix-up here: the backward re-reads the saved `update`, which must hold the split rows too)
         update = rspmm_forward(csr, relation, flat, "add", mul, add_rows=None if add_rows is None else add_rows.flatten(1),
                                boundary=boundary)
         update = update.view(shape)

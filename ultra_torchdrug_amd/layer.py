@@ -149,17 +149,13 @@ class _RelationalConvBase(nn.Module):
         fused = self._sum_layer(graph, input, shortcut)
         if fused is not None:
             return fused
-        update = self.message_and_aggregate(graph, input, input_is_boundary=input_is_boundary, may_defer=True)
-        deferred = None
-        if isinstance(update, tuple):           # the rspmm left its split rows to the epilogue kernel (deferred fix-up)
-            update, deferred = update
+        update = self.message_and_aggregate(graph, input, input_is_boundary=input_is_boundary)
         if self._fusable(input, update):
             ln = self.layer_norm
             return backend.get().combine(input, update, self.linear.weight, self.linear.bias,
                                       ln.weight if ln else None, ln.bias if ln else None,
                                       ln.eps if ln else 1e-5, relu=self.activation is F.relu, shortcut=shortcut,
-                                      reuse_update=True, deferred=deferred)       # `update` is this call's own temporary
-        assert deferred is None
+                                      reuse_update=True)       # `update` is this call's own temporary
         output = self.combine(input, update)
         return output + input if shortcut else output
 
@@ -252,9 +248,7 @@ class _RelationalConvBase(nn.Module):
         return (features.unsqueeze(-1) * scales.unsqueeze(-2)).flatten(-2)
 
     # ---- rspmm path (layer.py:111-182, :298-384) -------------------------------------------------------
-    def message_and_aggregate(self, graph, input, input_is_boundary=False, may_defer=False):
-        """``may_defer`` (``forward`` only, when the fused epilogue follows): the result may be ``(update, deferred)`` --
-        see ``functional.rspmm_forward(defer_fixup=True)``."""
+    def message_and_aggregate(self, graph, input, input_is_boundary=False):
         if graph.requires_grad or self.message_func == "rotate":
             return self.aggregate(graph, self.message(graph, input))
         if self.message_func not in self.message2mul:
@@ -293,13 +287,6 @@ class _RelationalConvBase(nn.Module):
                 # first layer: only the out-edges of the boundary rows carry non-zero messages (csrc/frontier.inc)
                 update = ops.rspmm_frontier(adjacency, relation_input, sparse_bound)
             elif fuse_bound:
-                defer = (may_defer and kind == "sum" and getattr(ops, "DEFER_FIXUP", False)
-                         and ops.deferral_supported(adjacency, input.shape[1]) and input.shape[1] == 64 * batch_size
-                         and self._fusable(input.view(len(input), batch_size, -1), input.view(len(input), batch_size, -1)))
-                if defer:
-                    update, deferred = ops.rspmm_forward(adjacency, relation_input, input, "add", mul, defer_fixup=True,
-                                                         **bound_args)
-                    return update.view(len(update), batch_size, -1), deferred
                 update = ops.rspmm_forward(adjacency, relation_input, input, "add", mul, **bound_args)
             elif bound and ops.accepts(input):      # training
                 sparse_train = getattr(graph, "boundary_sparse", None)

@@ -201,18 +201,6 @@ class Segments:
         return ctypes.byref(self.struct)
 
     @property
-    def long_index(self):
-        """int32 ``[n_rows]``: position of a split row in ``long_rows`` (``-1``: the row is not split) -- what a consumer
-        of a deferred fix-up (``functional.rspmm_forward(defer_fixup=True)`` -> ``combine_forward(deferred=...)``) looks a
-        node up in.  Built once per plan."""
-        if getattr(self, "_long_index", None) is None:
-            index = torch.full((self.n_rows,), -1, dtype=torch.int32, device=self.row.device)
-            if self.long_rows.shape[0]:
-                index[self.long_rows[:, 0].long()] = torch.arange(self.long_rows.shape[0], dtype=torch.int32, device=self.row.device)
-            self._long_index = index
-        return self._long_index
-
-    @property
     def plan_tensor(self):
         """The ``ultra_segments`` struct as a CPU uint8 tensor (shares the struct's memory): the form in which a plan
         crosses the PyTorch dispatcher to ``torch.ops.ultra_mi.rspmm_plan_*`` (csrc/torch_ext.cpp)."""
