@@ -682,59 +682,33 @@ struct CombineParams {
 // before the GEMM of the current tile and land while the matrix cores run -- with two waves per SIMD and no prefetch
 // the waves fall into step (both wait for HBM, then both want the MFMA pipe: 37 % MFMA busy, PMC).  PF = false: the
 // two-waves-per-SIMD form, for inputs of a few tiles per wave.
-// TWO = true (round 3, large inputs): TWO prefetching waves per SIMD.  One wave per SIMD runs its LDS staging, its 128
-// MFMAs and its LayerNorm / store phase one after the other (the matrix pipe idles a third of the time: 94 us for
-// 465 k rows against 49 us of MFMA and ~60 us of HBM time), and a second wave did not fit: the 64 x 128 weight alone is
-// 128 VGPRs, the prefetched tile 64.  Here the wave keeps only the weight rows of outputs 0..31 in registers (64 VGPRs);
-// the rows of outputs 32..63 sit ONCE per workgroup in LDS (a [32][132]-float image: the B fragment of a k-step group is
-// one conflict-free ds_read_b128 per lane, like the A fragment), which brings the kernel under 256 VGPRs: eight waves
-// per workgroup, two per SIMD, each with its own tile and its own prefetch, so that one wave's VALU / LDS phases run
-// under the other's MFMAs.  Same k order, same accumulators: the bits do not change.
-constexpr int kCbWaves2 = 8;
-
-template <bool PF, bool TWO = false>
-__global__ __launch_bounds__((TWO ? kCbWaves2 : kCbWaves) * 64, (PF && !TWO) ? 1 : 2) void combine_kernel(const CombineParams p) {
-    constexpr int WAVES = TWO ? kCbWaves2 : kCbWaves;
+template <bool PF>
+__global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(const CombineParams p) {
     extern __shared__ __attribute__((aligned(16))) float cb_lds[];
     const int lane = threadIdx.x & 63;
     const int wl = uniform(threadIdx.x >> 6);
     float *tile = cb_lds + wl * kCbTileFloats;
     const int i = lane & 31, h = lane >> 5;
     const long long n_tiles = (p.rows + kCbRows - 1) / kCbRows;
-    const long long wave_global = (long long)blockIdx.x * WAVES + wl;
-    const long long wave_total = (long long)gridDim.x * WAVES;
+    const long long wave_global = (long long)blockIdx.x * kCbWaves + wl;
+    const long long wave_total = (long long)gridDim.x * kCbWaves;
 
     // B operand fragments: lane (j = l & 31, h): W[j + 32 t][64 h + s], s = 0..63, t = 0, 1
-    float w0[64], w1[TWO ? 1 : 64];
+    float w0[64], w1[64];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(p.weight + (long long)i * 128 + 64 * h + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(p.weight + (long long)(i + 32) * 128 + 64 * h + 4 * q);
         w0[4 * q + 0] = a.x; w0[4 * q + 1] = a.y; w0[4 * q + 2] = a.z; w0[4 * q + 3] = a.w;
-        if constexpr (!TWO) {
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(p.weight + (long long)(i + 32) * 128 + 64 * h + 4 * q);
-            w1[4 * q + 0] = b.x; w1[4 * q + 1] = b.y; w1[4 * q + 2] = b.z; w1[4 * q + 3] = b.w;
-        }
+        w1[4 * q + 0] = b.x; w1[4 * q + 1] = b.y; w1[4 * q + 2] = b.z; w1[4 * q + 3] = b.w;
     }
     const float bias0 = p.bias[i], bias1 = p.bias[i + 32];
     // LayerNorm role of this lane: row = lane >> 1, columns [32 * (lane & 1), +32)
     const int ln_row = lane >> 1, ln_half = lane & 1;
     // gamma | beta in LDS behind the tiles (a global load per element inside the row loop costs more than the GEMM)
-    float *gb = cb_lds + WAVES * kCbTileFloats;
+    float *gb = cb_lds + kCbWaves * kCbTileFloats;
     if (p.gamma != nullptr && threadIdx.x < 128) gb[threadIdx.x] = threadIdx.x < 64 ? p.gamma[threadIdx.x] : p.beta[threadIdx.x - 64];
-    // TWO: weight rows 32..63 behind gamma | beta, rows padded like the activation tiles
-    float *w_hi = gb + 128;
-    if constexpr (TWO) {
-        for (int e = threadIdx.x; e < 32 * 32; e += WAVES * 64) {          // 32 rows x 32 float4
-            const int r = e >> 5, c4 = (e & 31) * 4;
-            *reinterpret_cast<f32x4 *>(w_hi + r * kCbStride + c4) = *reinterpret_cast<const f32x4 *>(p.weight + (long long)(r + 32) * 128 + c4);
-        }
-    }
     __syncthreads();
-    if constexpr (TWO) {
-        // the two waves of a SIMD run the same program: started together they reach their matrix phases together.
-        // Waves 4..7 start half a tile late (MI355X_MICROARCH.md, two waves per SIMD, item 9: by wave number >= 4)
-        if (wl >= 4) __builtin_amdgcn_s_sleep(48);
-    }
 
     const long long last = p.rows - 1;
     f32x4 pa[8], pb[8];     // PF: the staged rows of the tile about to be processed
@@ -775,17 +749,14 @@ __global__ __launch_bounds__((TWO ? kCbWaves2 : kCbWaves) * 64, (PF && !TWO) ? 1
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const f32x4 av = *reinterpret_cast<const f32x4 *>(tile + i * kCbStride + 64 * h + 4 * q);
-            f32x4 bv;
-            if constexpr (TWO) bv = *reinterpret_cast<const f32x4 *>(w_hi + i * kCbStride + 64 * h + 4 * q);
-            else bv = f32x4{w1[4 * q + 0], w1[4 * q + 1], w1[4 * q + 2], w1[4 * q + 3]};
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w0[4 * q + 0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w1[4 * q + 0], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w0[4 * q + 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w1[4 * q + 1], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w0[4 * q + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w1[4 * q + 2], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w0[4 * q + 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w1[4 * q + 3], acc1, 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all A-fragment reads done before `update` is overwritten
 
@@ -1163,7 +1134,6 @@ int launch_rowgroup(RowGroupParams &q, bool backward, int sum_op, int mul_op, bo
 
 bool g_no_rowgroup = false;
 bool g_no_concurrent_tiles = false;
-bool g_combine_one_wave = false;
 constexpr unsigned long long kConcurrentSliceBytes = 2560ull * 1024;      // slices of concurrently processed tiles per XCD
 constexpr bool TWO_GATHERS_KIND(int kind) { return kind == KIND_DREL; }
 
@@ -1414,7 +1384,6 @@ int ultra_rspmm_force_general_path(int on) {
     g_no_rowgroup = (on & 8) != 0;        // bit 3: chunked kernels where one row per group (rowgroup_kernel) would run
     g_wide_groups = (on & 16) != 0;       // bit 4: rowgroup_kernel with 32 / 64 lanes per row even for cache-sized inputs
     g_no_concurrent_tiles = (on & 32) != 0;   // bit 5: quad_kernel walks a label's column tiles one after the other
-    g_combine_one_wave = (on & 64) != 0;      // bit 6: combine_kernel with one wave per SIMD where two would run
     return ULTRA_OK;
 }
 
@@ -1688,29 +1657,21 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
     p.input = input; p.update = update; p.weight = weight; p.bias = bias; p.gamma = ln_weight; p.beta = ln_bias;
     p.out = out; p.rows = rows; p.eps = ln_eps; p.relu = relu; p.shortcut = shortcut;
     const long long n_tiles = (rows + kCbRows - 1) / kCbRows;
-    // at least ~4 tiles per wave: one workgroup per CU with the next tile prefetched under the GEMM.  From ~8 tiles per
-    // wave of the eight-wave form on: two waves per SIMD (the upper half of the weight in LDS, see combine_kernel)
+    long long blocks = (n_tiles + kCbWaves - 1) / kCbWaves;
+    // at least ~4 tiles per wave: one workgroup per CU, one wave per SIMD, next tile prefetched under the GEMM
     const bool prefetch = n_tiles >= (long long)di->n_cu * kCbWaves * 4;
-    const bool two = !g_combine_one_wave && n_tiles >= (long long)di->n_cu * kCbWaves2 * 4;
-    const int waves = two ? kCbWaves2 : kCbWaves;
-    long long blocks = (n_tiles + waves - 1) / waves;
-    const long long resident = (long long)di->n_cu * ((prefetch || two) ? 1 : 2);
+    const long long resident = (long long)di->n_cu * (prefetch ? 1 : 2);
     if (blocks > resident) blocks = resident;
     const size_t lds = (size_t)(kCbWaves * kCbTileFloats + 128) * sizeof(float);
-    const size_t lds_two = (size_t)(kCbWaves2 * kCbTileFloats + 128 + 32 * kCbStride) * sizeof(float);
     static bool attr_set[16] = {false};
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<true, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_two));
         attr_set[dev] = true;
     }
-    if (two)
-        hipLaunchKernelGGL((combine_kernel<true, true>), dim3((unsigned)blocks), dim3(kCbWaves2 * 64), lds_two, static_cast<hipStream_t>(stream), p);
-    else if (prefetch)
+    if (prefetch)
         hipLaunchKernelGGL(combine_kernel<true>, dim3((unsigned)blocks), dim3(kCbWaves * 64), lds, static_cast<hipStream_t>(stream), p);
     else
         hipLaunchKernelGGL(combine_kernel<false>, dim3((unsigned)blocks), dim3(kCbWaves * 64), lds, static_cast<hipStream_t>(stream), p);
