@@ -766,18 +766,17 @@ def main():
                            "(SURVEY 8d)" % (n_node * Fk * 4 / 1e6, achieved / 1e3)}
         configs = []
         roofline = dict(l2_line)
-        if world == 1:
-            del xk, rk
-            torch.cuda.empty_cache()
-            if args.configs:
-                configs = config_timings(dev, lib, DEFAULT_SEED, B, quick=args.steps < 100)
-            if args.stress:
-                roofline = stress_roofline(dev, lib)
-                roofline["l2"] = l2_line
-                configs.append({"config": 5, "name": "Synthetic KG 10M nodes / 100M edges / 1k relations, 64d inference (HBM-roofline stress)",
-                                "shape": roofline["workload"], "operator_fwd_ms": roofline["kernel_ms"],
-                                "edges_per_s": roofline["edges_per_s"], "frac_of_hbm_peak": roofline["frac"],
-                                "plan_build_s": roofline["plan_build_s"]})
+        del xk, rk
+        torch.cuda.empty_cache()
+        if world == 1 and args.configs:
+            configs = config_timings(dev, lib, DEFAULT_SEED, B, quick=args.steps < 100)
+        if args.stress:                             # rank 0 of any world: the other ranks wait at the final barrier
+            roofline = stress_roofline(dev, lib)
+            roofline["l2"] = l2_line
+            configs.append({"config": 5, "name": "Synthetic KG 10M nodes / 100M edges / 1k relations, 64d inference (HBM-roofline stress)",
+                            "shape": roofline["workload"], "operator_fwd_ms": roofline["kernel_ms"],
+                            "edges_per_s": roofline["edges_per_s"], "frac_of_hbm_peak": roofline["frac"],
+                            "plan_build_s": roofline["plan_build_s"]})
         result = {
             "metric": "edges aggregated/sec, FB15k237-shaped 6L x 64d rspmm Bellman-Ford (predict: 18 rspmm/batch)",
             "value": visited / elapsed,
