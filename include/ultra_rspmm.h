@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_RSPMM_ABI_VERSION 3
+#define ULTRA_RSPMM_ABI_VERSION 4
 
 /* sum= / mul= of generalized_rspmm (layer.py:134-167: sum in {"add","max","min"}, mul in {"mul","add"}) */
 enum ultra_sum_op { ULTRA_SUM_ADD = 0, ULTRA_SUM_MIN = 1, ULTRA_SUM_MAX = 2 };
@@ -219,6 +219,16 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
                               const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
                               float *out, int64_t rows, int64_t dim, void *stream);
 
+/* The same epilogue for the FIRST layer of a Bellman-Ford, whose `input` is the boundary itself (ultra/model.py:116-120):
+ * row (v, q) of `input` -- rows = n_nodes * n_query, q fastest -- is boundary_value[q, :] where v == boundary_node[q] and
+ * +0 elsewhere (what zeros + scatter_add_ build, ultra/model.py:106-107).  The kernel synthesises those rows instead of
+ * reading an (N, B, 64) tensor that is zero outside B rows; identical bits to ultra_combine_forward_f32 on the dense tensor.
+ *   boundary_node : int32 [n_query]     boundary_value : fp32 [n_query, 64] (16-byte aligned) */
+int ultra_combine_forward_boundary_f32(const int32_t *boundary_node, const float *boundary_value, int64_t n_query,
+                                       const float *update, const float *weight, const float *bias, const float *ln_weight,
+                                       const float *ln_bias, float ln_eps, int relu, int shortcut, float *out, int64_t rows,
+                                       int64_t dim, void *stream);
+
 
 /*
  * Backward of the fused epilogue above (training): replaces what autograd derives for the reference's
@@ -288,11 +298,24 @@ int ultra_score_forward_f32(const float *hidden, const float *query, const float
  * = `relation_projection` (2-layer MLP) of GeneralizedRelationalConvNBFMod followed by the (B, R, D) -> (R, B*D)
  * transpose (ultra/layer.py:228,318-319,325-326), which ultra/model.py:120-130 triggers once per layer.
  *   relation : fp32 [batch, n_rel, 64];  w1 / b1 / w2 / b2 / out : HOST arrays of n_layers DEVICE pointers
- *   (weights [64, 64] as nn.Linear.weight, biases [64], out[l] [n_rel, batch, 64]).  Bit-identical to two
- *   ultra_linear_forward_f32 calls + the transpose. */
+ *   (weights [64, 64] as nn.Linear.weight, biases [64], out[l] [n_rel, batch * repeat, 64]).  Bit-identical to two
+ *   ultra_linear_forward_f32 calls + the transpose.  repeat >= 1: every projected row (b, r) is written to the query
+ *   blocks b, b + batch, ...: the tables of `torch.cat([relation] * repeat)` (full-batch evaluation scores the tail and
+ *   the head queries of a batch over the same relation representations, ultra/task.py:249-259) at the cost of one. */
 int ultra_relation_project_f32(const float *relation, const float *const *w1, const float *const *b1,
                                const float *const *w2, const float *const *b2, float *const *out, int64_t n_layers,
-                               int64_t batch, int64_t n_rel, int64_t dim, void *stream);
+                               int64_t batch, int64_t repeat, int64_t n_rel, int64_t dim, void *stream);
+
+/* The index glue between the relation stack and the entity stack for one evaluation batch, in one launch: from the B
+ * triples batch[b] = (h, t, r) (int64 [B, 3], the reference's column order, ultra/task.py:123) and the conditioned
+ * relation representations rel_rep [B, n_rel2, 64] (n_rel2 = 2 * n_base_rel relations incl. inverses), the 2B tail-form
+ * queries of full-batch evaluation (ultra/task.py:249-259, ultra/model.py:76-83,101-114):
+ *     q <  B : anchor = h[q],     relation = r[q]                    q >= B : anchor = t[q - B], relation = r[q - B] + n_base_rel
+ *     query[q, :] = rel_rep[q mod B, relation[q], :]
+ * Outputs: anchor int64 [2B], anchor32 int32 [2B], relation int64 [2B], query fp32 [2B, 64].  Plain copies: what the
+ * reference's cat / add / arange / index kernels produce. */
+int ultra_prepare_queries(const int64_t *batch, const float *rel_rep, int64_t n_batch, int64_t n_rel2, int64_t n_base_rel,
+                          int64_t *anchor, int32_t *anchor32, int64_t *relation, float *query, void *stream);
 
 /* Backward of ultra_relation_project_f32 for all layers in one launch (training):
  *     d_w1[l], d_b1[l], d_w2[l], d_b2[l]   gradients of the layer's four parameters ([64, 64] / [64], overwritten)

@@ -430,3 +430,59 @@ def test_gradient_reducer_over_rccl_single_rank_group():
             reducer.remove_hooks()
     finally:
         dist.destroy_process_group()
+
+
+def test_fused_inference_sequence_equals_the_layer_by_layer_path():
+    """model.score_both_sides / rel_model._fast_bellmanford (one query-preparation kernel, projection tables computed once
+    for both sides, the first layer's boundary never materialised, cached relation tables) against the general path
+    through layer.forward with the switch off: identical scores; and its pieces against their torch formulations."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    for shape in ("S-tiny", (1200, 9000, 12)):
+        task, triples = _build(shape)
+        task.to(dev)
+        batch = torch.from_numpy(triples[:16]).to(dev)
+        calls = []
+        real = UF.prepare_queries
+        UF.prepare_queries = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            with torch.no_grad():
+                fast = task.predict(batch)
+                assert len(calls) == 1
+                UF.FAST_INFERENCE = False
+                general = task.predict(batch)
+                assert len(calls) == 1
+        finally:
+            UF.FAST_INFERENCE = True
+            UF.prepare_queries = real
+        assert torch.equal(fast, general)
+    # the pieces
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    B, R = 16, 12
+    rel_rep = torch.randn(B, 2 * R, 64, generator=gen).to(dev)
+    trip = torch.stack([torch.randint(0, 1200, (B,), generator=gen), torch.randint(0, 1200, (B,), generator=gen),
+                        torch.randint(0, R, (B,), generator=gen)], dim=1).to(dev)
+    anchor, anchor32, relation, query = UF.prepare_queries(trip, rel_rep, R)
+    h, t, r = trip.t()
+    assert torch.equal(anchor, torch.cat([h, t])) and torch.equal(anchor32.long(), anchor)
+    assert torch.equal(relation, torch.cat([r, r + R]))
+    assert torch.equal(query, torch.cat([rel_rep, rel_rep])[torch.arange(2 * B, device=dev), relation])       # model.py:105
+    lins = [(torch.nn.Linear(64, 64).to(dev), torch.nn.Linear(64, 64).to(dev)) for _ in range(3)]
+    weights = [(a.weight, a.bias, b.weight, b.bias) for a, b in lins]
+    with torch.no_grad():
+        once = UF.relation_project(rel_rep, weights, repeat=2)
+        twice = UF.relation_project(torch.cat([rel_rep, rel_rep]), weights)
+    assert all(torch.equal(a, b) for a, b in zip(once, twice))
+    n = 300
+    node = torch.randint(0, n, (2 * B,), generator=gen).to(torch.int32).to(dev)
+    node[3] = node[5]                                          # two queries starting at one node
+    update = torch.randn(n, 2 * B, 64, generator=gen).to(dev)
+    dense = torch.zeros(n, 2 * B, 64, device=dev)
+    dense[node.long(), torch.arange(2 * B, device=dev)] = query
+    lin, norm = torch.nn.Linear(128, 64).to(dev), torch.nn.LayerNorm(64).to(dev)
+    with torch.no_grad():
+        for shortcut in (True, False):
+            want = UF.combine_forward(dense, update, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, shortcut)
+            got = UF.combine_forward(None, update, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, shortcut,
+                                     input_boundary=(node, query))
+            assert torch.equal(got, want)

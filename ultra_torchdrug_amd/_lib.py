@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ULTRA_RSPMM_LIB: load another build of the same ABI (kernel A/B runs, tools/kbench.py)
 LIB_PATH = os.environ.get("ULTRA_RSPMM_LIB") or os.path.join(_HERE, "libultra_rspmm.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SUM_OPS = {"add": 0, "min": 1, "max": 2}
 MUL_OPS = {"mul": 0, "add": 1}
@@ -58,6 +58,7 @@ EXPORTS = (
     "ultra_rspmm_backward_accumulate_f32",
     "ultra_rspmm_backward_weight_f32",
     "ultra_combine_forward_f32",
+    "ultra_combine_forward_boundary_f32",
     "ultra_combine_backward_waves",
     "ultra_combine_backward_f32",
     "ultra_combine_dxdu_f32",
@@ -72,6 +73,7 @@ EXPORTS = (
     "ultra_filtered_rank_keys",
     "ultra_strict_negative",
     "ultra_edge_removal_weights",
+    "ultra_prepare_queries",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
     "ultra_relcsr_plan_temp_bytes",
@@ -141,6 +143,10 @@ def load():
     lib.ultra_rspmm_backward_weight_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
     lib.ultra_combine_forward_f32.restype = i32
     lib.ultra_combine_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, i64, vp]
+    lib.ultra_combine_forward_boundary_f32.restype = i32
+    lib.ultra_combine_forward_boundary_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, i64, vp]
+    lib.ultra_prepare_queries.restype = i32
+    lib.ultra_prepare_queries.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]
     lib.ultra_combine_backward_waves.restype = i32
     lib.ultra_combine_backward_waves.argtypes = [i32, i64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.ultra_combine_backward_f32.restype = i32
@@ -157,7 +163,7 @@ def load():
     lib.ultra_score_forward_f32.restype = i32
     lib.ultra_score_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
     lib.ultra_relation_project_f32.restype = i32
-    lib.ultra_relation_project_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]
+    lib.ultra_relation_project_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]
     lib.ultra_relation_project_backward_blocks.restype = i32
     lib.ultra_relation_project_backward_blocks.argtypes = [i32, i64, i64, i64, vp]
     lib.ultra_relation_project_backward_f32.restype = i32

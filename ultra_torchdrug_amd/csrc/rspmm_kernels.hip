@@ -676,6 +676,11 @@ struct CombineParams {
     float eps;
     int relu;
     int shortcut;
+    // first layer of a Bellman-Ford (ultra_combine_forward_boundary_f32): `input` IS the boundary -- zero outside row
+    // in_bnode[q] of query block q (ultra/model.py:106-107) -- and is synthesised instead of read; NULL otherwise
+    const int32_t *in_bnode;     // [rpn]
+    const float *in_bvec;        // [rpn, 64]
+    int rpn;                     // rows per node = number of queries
 };
 
 // PF = true (large inputs): one wave per SIMD (up to 512 VGPRs); the NEXT tile's 16 KiB are fetched into registers
@@ -718,7 +723,14 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
             const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
             long long gr = t * kCbRows + r;
             gr = gr < last ? gr : last;
-            pa[q] = *reinterpret_cast<const f32x4 *>(p.input + gr * 64 + c);
+            if (p.in_bnode == nullptr) {
+                pa[q] = *reinterpret_cast<const f32x4 *>(p.input + gr * 64 + c);
+            } else {                 // row (node, query) of the boundary: the query's value at its own node, +0 elsewhere
+                const long long node = gr / p.rpn;
+                const int query = (int)(gr - node * p.rpn);
+                const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                pa[q] = ((int)node == p.in_bnode[query]) ? *reinterpret_cast<const f32x4 *>(p.in_bvec + query * 64 + c) : zero;
+            }
             pb[q] = *reinterpret_cast<const f32x4 *>(p.update + gr * 64 + c);
         }
     };
@@ -1639,24 +1651,13 @@ int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd, const float *rela
 }
 
 
-int ultra_combine_forward_f32(const float *input, const float *update, const float *weight, const float *bias,
-                              const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                              float *out, int64_t rows, int64_t dim, void *stream) {
-    if (dim != 64) return ULTRA_ERR_BAD_SHAPE;     // the shipped architecture: 64 -> 64 with a 128-wide concat
-    if (rows < 0) return ULTRA_ERR_BAD_SHAPE;
-    if (rows == 0) return ULTRA_OK;
-    if (input == nullptr || update == nullptr || weight == nullptr || bias == nullptr || out == nullptr)
-        return ULTRA_ERR_NULL_POINTER;
-    if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
+static int combine_launch(const CombineParams &p, void *stream) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     DeviceInfo *di = nullptr;
     int rc = device_info(dev, &di);
     if (rc) return rc;
-    CombineParams p;
-    p.input = input; p.update = update; p.weight = weight; p.bias = bias; p.gamma = ln_weight; p.beta = ln_bias;
-    p.out = out; p.rows = rows; p.eps = ln_eps; p.relu = relu; p.shortcut = shortcut;
-    const long long n_tiles = (rows + kCbRows - 1) / kCbRows;
+    const long long n_tiles = (p.rows + kCbRows - 1) / kCbRows;
     long long blocks = (n_tiles + kCbWaves - 1) / kCbWaves;
     // at least ~4 tiles per wave: one workgroup per CU, one wave per SIMD, next tile prefetched under the GEMM
     const bool prefetch = n_tiles >= (long long)di->n_cu * kCbWaves * 4;
@@ -1677,6 +1678,39 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
         hipLaunchKernelGGL(combine_kernel<false>, dim3((unsigned)blocks), dim3(kCbWaves * 64), lds, static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
+}
+
+int ultra_combine_forward_f32(const float *input, const float *update, const float *weight, const float *bias,
+                              const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                              float *out, int64_t rows, int64_t dim, void *stream) {
+    if (dim != 64) return ULTRA_ERR_BAD_SHAPE;     // the shipped architecture: 64 -> 64 with a 128-wide concat
+    if (rows < 0) return ULTRA_ERR_BAD_SHAPE;
+    if (rows == 0) return ULTRA_OK;
+    if (input == nullptr || update == nullptr || weight == nullptr || bias == nullptr || out == nullptr)
+        return ULTRA_ERR_NULL_POINTER;
+    if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
+    CombineParams p{};
+    p.input = input; p.update = update; p.weight = weight; p.bias = bias; p.gamma = ln_weight; p.beta = ln_bias;
+    p.out = out; p.rows = rows; p.eps = ln_eps; p.relu = relu; p.shortcut = shortcut;
+    return combine_launch(p, stream);
+}
+
+int ultra_combine_forward_boundary_f32(const int32_t *boundary_node, const float *boundary_value, int64_t n_query,
+                                       const float *update, const float *weight, const float *bias, const float *ln_weight,
+                                       const float *ln_bias, float ln_eps, int relu, int shortcut, float *out, int64_t rows,
+                                       int64_t dim, void *stream) {
+    if (dim != 64 || rows < 0 || n_query <= 0 || n_query > 0x7fffffffLL || rows % n_query != 0) return ULTRA_ERR_BAD_SHAPE;
+    if (rows == 0) return ULTRA_OK;
+    if (boundary_node == nullptr || boundary_value == nullptr || update == nullptr || weight == nullptr || bias == nullptr ||
+        out == nullptr)
+        return ULTRA_ERR_NULL_POINTER;
+    if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (reinterpret_cast<uintptr_t>(boundary_value) & 15u) return ULTRA_ERR_BAD_SHAPE;
+    CombineParams p{};
+    p.input = nullptr; p.update = update; p.weight = weight; p.bias = bias; p.gamma = ln_weight; p.beta = ln_bias;
+    p.out = out; p.rows = rows; p.eps = ln_eps; p.relu = relu; p.shortcut = shortcut;
+    p.in_bnode = boundary_node; p.in_bvec = boundary_value; p.rpn = (int)n_query;
+    return combine_launch(p, stream);
 }
 
 }  // extern "C"

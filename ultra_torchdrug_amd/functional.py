@@ -264,12 +264,36 @@ def rspmm_backward_weight(csr, relation, input, output, output_grad, sum="add", 
 
 
 def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,
-                    reuse_update=False):
+                    reuse_update=False, input_boundary=None):
     """Fused ``combine`` (+ shortcut) of one layer, forward only: ``[input +] relu(LN(Linear(cat[input, update])))``
     (``ultra/layer.py:386-392``, ``ultra/model.py:126-127``).  ``input`` / ``update``: ``(..., 64)`` fp32 on the GPU.
     ``reuse_update``: the caller owns ``update`` and does not need it afterwards -- the result is written over it
     (every 32-row tile is read completely before it is written), which keeps a layer's working set at two
     ``(N, B, 64)`` tensors instead of three."""
+    if input_boundary is not None:
+        # first layer: `input` is the boundary (model.py:116-120), given as (node int32 (B,), value fp32 (B, 64)); the kernel
+        # synthesises its rows -- row (v, q) = value[q] where v == node[q], +0 elsewhere -- instead of reading (N, B, 64) zeros
+        if input is not None:
+            raise RuntimeError("combine_forward: give the layer input either dense or as input_boundary, not both")
+        b_node, b_value = input_boundary
+        b_value = b_value.contiguous()
+        n_query = b_node.shape[0]
+        if (update.dim() != 3 or update.shape[1] != n_query or update.shape[-1] != 64 or tuple(weight.shape) != (64, 128)
+                or b_node.dtype != torch.int32 or not b_node.is_contiguous() or b_value.shape != (n_query, 64)):
+            raise RuntimeError("combine_forward(input_boundary=...): update (N, B, 64), node int32 (B,), value (B, 64)")
+        tensors = [update, weight, bias, b_value] + ([ln_weight, ln_bias] if ln_weight is not None else [])
+        if any(t.dtype != torch.float32 or not t.is_cuda or t.device != update.device for t in tensors) or b_node.device != update.device:
+            raise RuntimeError("combine_forward needs fp32 tensors on one HIP device (no CPU fallback)")
+        update = update.contiguous()
+        out = update if reuse_update else torch.empty_like(update)
+        lib = _lib.load()
+        with torch.cuda.device(update.device):
+            _lib.check(lib.ultra_combine_forward_boundary_f32(
+                b_node.data_ptr(), b_value.data_ptr(), n_query, update.data_ptr(), weight.contiguous().data_ptr(),
+                bias.contiguous().data_ptr(), ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
+                ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)),
+                int(bool(shortcut)), out.data_ptr(), update.numel() // 64, 64, _stream()))
+        return out
     if input.shape != update.shape or input.shape[-1] != 64 or tuple(weight.shape) != (64, 128):
         raise RuntimeError("combine_forward handles 64 -> 64 layers with a (64, 128) weight; got input %s, update %s, "
                            "weight %s" % (tuple(input.shape), tuple(update.shape), tuple(weight.shape)))
@@ -331,11 +355,13 @@ def score_all_entities(hidden, query, w1, b1, w2, b2):
     return out
 
 
-def relation_project(relation, weights):
+def relation_project(relation, weights, repeat=1):
     """All layers' relation projections in one launch.  ``relation``: fp32 ``(B, R, 64)``; ``weights``: one
     ``(w1, b1, w2, b2)`` per layer (``nn.Linear`` weights ``(64, 64)`` / biases ``(64,)`` of the 2-layer
     ``relation_projection`` MLP, ``ultra/layer.py:228,318-319``).  Returns one ``(R, B * 64)`` table per layer
-    -- ``relation_projection(relation).transpose(0, 1).flatten(1)`` (``layer.py:325-326``), bit for bit."""
+    -- ``relation_projection(relation).transpose(0, 1).flatten(1)`` (``layer.py:325-326``), bit for bit.
+    ``repeat``: the tables of ``torch.cat([relation] * repeat)`` -- ``(R, repeat * B * 64)``, query block ``b + j B`` a copy of
+    block ``b`` -- computed once (full-batch evaluation: tail and head queries share the relation representations)."""
     import ctypes
     relation = relation.contiguous()
     if relation.dim() != 3 or relation.shape[-1] != 64 or relation.dtype != torch.float32 or not relation.is_cuda:
@@ -350,7 +376,8 @@ def relation_project(relation, weights):
                 raise RuntimeError("relation_project: 64 -> 64 -> 64 fp32 projections only")
             keep.append(t)
             cols[k].append(t.data_ptr())
-    outs = [torch.empty(n_rel, batch * 64, dtype=torch.float32, device=relation.device) for _ in range(n)]
+    repeat = int(repeat)
+    outs = [torch.empty(n_rel, repeat * batch * 64, dtype=torch.float32, device=relation.device) for _ in range(n)]
     if n == 0 or relation.numel() == 0:
         return outs
     arr = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
@@ -358,7 +385,7 @@ def relation_project(relation, weights):
     with torch.cuda.device(relation.device):
         _lib.check(lib.ultra_relation_project_f32(
             relation.data_ptr(), arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]),
-            arr([o.data_ptr() for o in outs]), n, batch, n_rel, 64, _stream()))
+            arr([o.data_ptr() for o in outs]), n, batch, repeat, n_rel, 64, _stream()))
     return outs
 
 
@@ -410,6 +437,33 @@ def relation_project_train(relation, weights):
         raise RuntimeError("relation_project_train: at most 8 layers per call")
     flat = [t for layer_weights in weights for t in layer_weights]
     return list(_ProjectFunction.apply(relation, *flat))
+
+
+def prepare_queries(batch, rel_rep, n_base_rel):
+    """The 2B tail-form queries of one full-batch evaluation step in ONE launch (``ultra_prepare_queries``): ``batch`` int64
+    ``(B, 3)`` rows of (h, t, r); ``rel_rep`` fp32 ``(B, 2 R, 64)`` (the relation stack's output for the batch's relations).
+    Returns ``(anchor int64 (2B,), anchor32 int32 (2B,), relation int64 (2B,), query fp32 (2B, 64))`` -- what
+    ``cat([h, t])``, ``cat([r, r + R])`` and ``cat([rel_rep, rel_rep])[arange(2B), relation]`` give (task.py:249-259,
+    model.py:76-83,101-105), nine index kernels of a few microseconds each otherwise."""
+    batch = batch.contiguous()
+    rel_rep = rel_rep.contiguous()
+    n_batch = batch.shape[0]
+    if (batch.dtype != torch.int64 or batch.dim() != 2 or batch.shape[1] != 3 or not batch.is_cuda or rel_rep.dtype != torch.float32
+            or rel_rep.dim() != 3 or rel_rep.shape[0] != n_batch or rel_rep.shape[2] != 64 or rel_rep.device != batch.device
+            or 2 * int(n_base_rel) != rel_rep.shape[1]):
+        raise RuntimeError("prepare_queries: batch int64 (B, 3) and rel_rep fp32 (B, 2 * n_base_rel, 64) on one HIP device")
+    dev = batch.device
+    anchor = torch.empty(2 * n_batch, dtype=torch.int64, device=dev)
+    anchor32 = torch.empty(2 * n_batch, dtype=torch.int32, device=dev)
+    relation = torch.empty(2 * n_batch, dtype=torch.int64, device=dev)
+    query = torch.empty(2 * n_batch, 64, dtype=torch.float32, device=dev)
+    if n_batch:
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_prepare_queries(batch.data_ptr(), rel_rep.data_ptr(), n_batch, rel_rep.shape[1], int(n_base_rel),
+                                                 anchor.data_ptr(), anchor32.data_ptr(), relation.data_ptr(), query.data_ptr(),
+                                                 _stream()))
+    return anchor, anchor32, relation, query
 
 
 def filtered_rank(pred, target, filt_ptr=None, filt_node=None):
@@ -595,6 +649,12 @@ class _CombineFunction(torch.autograd.Function):
         if has_ln and needs[5]:
             d_b = db_p.sum(0)
         return d_input, d_update, d_weight, d_bias, d_g, d_b, None, None, None
+
+
+# The fused inference fast paths of model.py / rel_model.py (one query-preparation kernel, projection tables computed once
+# for both sides, the first layer's boundary never materialised) run on this backend; the oracle-backed backend of the
+# tests keeps the reference's op-by-op path, so the two are compared against each other.
+FAST_INFERENCE = __import__("os").environ.get("ULTRA_FAST_INFERENCE", "1") != "0"
 
 
 def combine(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,

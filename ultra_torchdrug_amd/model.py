@@ -164,6 +164,74 @@ class TransferNBFNet(nn.Module):
         tables = ops.relation_project_train(relation, weights) if training else ops.relation_project(relation, weights)
         return {id(conv): table for conv, table in zip(convs, tables)}
 
+    def _fast_stack(self):
+        """The layers' parameters when the fused inference sequence of :meth:`score_both_sides` covers this model (the
+        shipped architecture: 64-d DistMult / sum layers with LayerNorm or none, relu or none, projected relations, shortcut
+        per layer as :meth:`bellmanford` applies it); ``None`` otherwise."""
+        F = torch.nn.functional
+        if not self.layers or self.concat_hidden or self.symmetric or not layer.FRONTIER_FIRST_LAYER:
+            return None
+        stack = []
+        for conv in self.layers:
+            mlp = getattr(conv, "relation_projection", None)
+            ok = (isinstance(conv, layer.GeneralizedRelationalConvNBFMod) and conv.project and conv.message_func == "distmult"
+                  and conv.aggregate_func == "sum" and conv.input_dim == 64 and conv.output_dim == 64
+                  and tuple(conv.linear.weight.shape) == (64, 128) and conv.linear.bias is not None
+                  and (conv.activation is F.relu or not conv.activation)
+                  and (conv.layer_norm is None or (conv.layer_norm.elementwise_affine and conv.layer_norm.bias is not None))
+                  and mlp is not None and len(mlp.layers) == 2 and not mlp.short_cut and mlp.activation is F.relu
+                  and all(l.in_features == 64 and l.out_features == 64 and l.bias is not None for l in mlp.layers))
+            if not ok:
+                return None
+            ln = conv.layer_norm
+            stack.append(dict(
+                project=(mlp.layers[0].weight, mlp.layers[0].bias, mlp.layers[1].weight, mlp.layers[1].bias),
+                combine=(conv.linear.weight, conv.linear.bias, ln.weight if ln else None, ln.bias if ln else None,
+                         ln.eps if ln else 1e-5, conv.activation is F.relu)))
+        return stack
+
+    def score_both_sides(self, graph, rel_rep, batch):
+        """Full-batch evaluation of one batch of triples, tails and heads at once: scores ``(2 B, N)`` of every entity for the
+        queries ``(h, r, ?)`` (rows ``0 .. B-1``) and ``(t, r + R, ?)`` (rows ``B .. 2B-1``) -- what :meth:`score_all_entities`
+        returns for ``cat([h, t])``, ``cat([r, r + R])`` and ``cat([rel_rep, rel_rep])`` (task.py:249-259, model.py:76-83),
+        with the index glue of that path folded away: ONE kernel prepares the 2B queries, the relation projections are
+        computed once for both sides, and the first layer's boundary is never materialised (the frontier kernel and the
+        epilogue read it in its sparse form).  Same kernels on the same operands as the general path: identical bits
+        (the parity tests compare this path on the HIP backend with the op-by-op path on the oracle backend).
+        ``None`` when the fast sequence does not cover the model / backend / mode: the caller takes the general path."""
+        ops = backend.get()
+        if (not getattr(ops, "FAST_INFERENCE", False) or torch.is_grad_enabled() or not graph.num_relation
+                or not self._fused_head_ok(batch, None) or rel_rep.dim() != 3 or rel_rep.shape[0] != batch.shape[0]
+                or rel_rep.shape[-1] != 64 or rel_rep.dtype != torch.float32 or rel_rep.shape[1] != 2 * graph.num_relation):
+            return None
+        stack = self._fast_stack()
+        if stack is None:
+            return None
+        und = self._undirected(graph)
+        csr = und.relcsr
+        n_query = 2 * batch.shape[0]
+        if not ops.frontier_supported("add", "mul", 64 * n_query):
+            return None
+        anchor, anchor32, relation, query = ops.prepare_queries(batch, rel_rep, graph.num_relation)
+        tables = ops.relation_project(rel_rep, [entry["project"] for entry in stack], repeat=2)
+        if not layer._frontier_tables_finite(tables[0]):         # (eager calls only) the first layer's shortcut needs finite tables
+            return None
+        boundary = (anchor32, query)
+        n_node = und.num_node
+        hidden = None
+        for i, entry in enumerate(stack):
+            w, b, g, beta, eps, relu = entry["combine"]
+            if i == 0:
+                update = ops.rspmm_frontier(csr, tables[0], boundary).view(n_node, n_query, 64)
+                hidden = ops.combine_forward(None, update, w, b, g, beta, eps, relu, self.short_cut, reuse_update=True,
+                                             input_boundary=boundary)
+            else:
+                update = ops.rspmm_forward(csr, tables[i], hidden.flatten(1), "add", "mul", boundary=boundary)
+                hidden = ops.combine_forward(hidden, update.view(n_node, n_query, 64), w, b, g, beta, eps, relu, self.short_cut,
+                                             reuse_update=True)
+        first, second = self.mlp.layers
+        return ops.score_all_entities(hidden, query, first.weight, first.bias, second.weight, second.bias)
+
     def score_all_entities(self, graph, rel_query_list, h_index, r_index):
         """Scores ``(Q, N)`` of every entity as the tail of the queries ``(h_index[q], r_index[q], ?)``, both 1-D and
         ALREADY in tail form (``r_index`` in ``[0, 2R)`` over the graph with inverse edges): what ``forward`` computes

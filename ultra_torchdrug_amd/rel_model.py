@@ -120,7 +120,56 @@ class CustomNBFNetFull(CustomNBFNet):
         if learn_query:
             self.learnable_q = nn.Embedding(1, self.dims[0])
 
+    def _fast_bellmanford(self, graph, h_index):
+        """Inference on the HIP backend with the shipped relation model (64-d DistMult / sum layers over the 4 edge types,
+        shared relation embeddings, LayerNorm, shortcut): the sequence :meth:`bellmanford` runs through the layers, with
+        the boundary never materialised (frontier kernel + sparse-input epilogue) and the relation tables of all layers
+        tiled by one copy.  Same kernels on the same operands: identical bits.  ``None``: not applicable."""
+        F = torch.nn.functional
+        ops = layer.backend.get()
+        if (not getattr(ops, "FAST_INFERENCE", False) or torch.is_grad_enabled() or self.learn_query or self.concat_hidden
+                or not layer.FRONTIER_FIRST_LAYER or not ops.accepts(h_index) or not self.layers):
+            return None
+        for conv in self.layers:
+            ok = (isinstance(conv, layer.GeneralizedRelationalConvNBF) and not conv.dependent and conv.message_func == "distmult"
+                  and conv.aggregate_func == "sum" and conv.input_dim == 64 and conv.output_dim == 64
+                  and tuple(conv.linear.weight.shape) == (64, 128) and conv.linear.bias is not None
+                  and (conv.activation is F.relu or not conv.activation) and conv.relation.weight.is_cuda
+                  and (conv.layer_norm is None or (conv.layer_norm.elementwise_affine and conv.layer_norm.bias is not None)))
+            if not ok:
+                return None
+            assert graph.num_relation == conv.num_relation              # layer.py:53,115
+        n_query = h_index.shape[0]
+        if not ops.frontier_supported("add", "mul", 64 * n_query):
+            return None
+        # (nothing is cached across calls: a captured hipGraph holds raw pointers to every tensor it read, and a cache
+        # rebuilt for another batch size -- or stale after a weight update -- would silently invalidate it)
+        weights = [conv.relation.weight for conv in self.layers]
+        n_rel, dim = weights[0].shape
+        tables = torch.stack(weights).unsqueeze(2).expand(-1, -1, n_query, -1).reshape(len(weights), n_rel, n_query * dim)
+        if not layer._frontier_tables_finite(tables[0]):
+            return None
+        query = torch.ones(n_query, self.dims[0], device=h_index.device)
+        boundary = (h_index.to(torch.int32), query)
+        csr = graph.relcsr
+        n_node = graph.num_node
+        hidden = None
+        for i, conv in enumerate(self.layers):
+            ln = conv.layer_norm
+            args = (conv.linear.weight, conv.linear.bias, ln.weight if ln else None, ln.bias if ln else None,
+                    ln.eps if ln else 1e-5, conv.activation is F.relu, self.short_cut)
+            if i == 0:
+                update = ops.rspmm_frontier(csr, tables[0], boundary).view(n_node, n_query, 64)
+                hidden = ops.combine_forward(None, update, *args, reuse_update=True, input_boundary=boundary)
+            else:
+                update = ops.rspmm_forward(csr, tables[i], hidden.flatten(1), "add", "mul", boundary=boundary)
+                hidden = ops.combine_forward(hidden, update.view(n_node, n_query, 64), *args, reuse_update=True)
+        return {"node_feature": hidden.transpose(1, 0)}
+
     def bellmanford(self, graph, h_index, separate_grad=False):
+        fast = self._fast_bellmanford(graph, h_index)
+        if fast is not None:
+            return fast
         dev = h_index.device
         if self.learn_query:
             query = self.learnable_q.weight.expand(h_index.shape[0], self.dims[0])

@@ -298,6 +298,10 @@ class KnowledgeGraphCompletion(nn.Module):
 
         if all_loss is None and self.full_batch_eval and self.fuse_sides:         # evaluation, both sides at once
             # rows 0..B-1: (h, r, ?);  rows B..2B-1: (?, r, t) in tail form = (t, r + R, ?)  (model.py:76-83)
+            if len(rel_inputs) == 1 and hasattr(self.model, "score_both_sides"):
+                pred = self.model.score_both_sides(self.fact_graph, rel_inputs[0], batch)      # the fused sequence, if it applies
+                if pred is not None:
+                    return pred.view(2, batch_size, self.num_entity).transpose(0, 1).contiguous()    # (B, 2, N)
             rel2 = [torch.cat([r, r]) for r in rel_inputs]
             pred = self.model.score_all_entities(self.fact_graph, rel2, torch.cat([pos_h_index, pos_t_index]),
                                                  torch.cat([pos_r_index, pos_r_index + self.fact_graph.num_relation]))
