@@ -234,3 +234,35 @@ def test_multi_graph_pretraining_step_at_full_size():
                    if p.grad is None and "dist_embed" not in k and "rel_models.0.model.mlp" not in k]
         assert not missing, missing
     assert seen == set(PRETRAIN_3G)
+
+
+def test_multi_graph_graphed_steps_equal_eager_steps():
+    """engine.GraphedMultiGraphTrainStep: one captured step per graph context over ONE set of parameters and ONE optimizer
+    (each capture re-binds the gradient tensors its backward writes).  A sequence of steps that hops between the three
+    graphs must leave exactly the parameters of the same eager steps (the graphs draw their own negatives: replayed)."""
+    import copy
+    from ultra_torchdrug_amd import engine
+    dev = _dev()
+    task = _multi_graph_task(scale=8, num_negative=32).to(dev).train()
+    state = copy.deepcopy(task.state_dict())
+    twin = _multi_graph_task(scale=8, num_negative=32).to(dev).train()
+    twin.load_state_dict(state)
+    gen = torch.Generator().manual_seed(13)
+    order = ["fb15k237", "wn18rr", "fb15k237", "codexm", "wn18rr", "codexm", "fb15k237"]
+    batches = []
+    for gid in order:
+        fact = task.contexts[gid]["fact_graph"].edge_list
+        batches.append((fact[torch.randperm(len(fact), generator=gen)[:16].to(dev)], gid))
+    opt_g = torch.optim.AdamW(twin.parameters(), lr=1e-3)
+    graphed = engine.GraphedMultiGraphTrainStep(twin, opt_g, 16)
+    opt_e = torch.optim.AdamW(task.parameters(), lr=1e-3)
+    for batch in batches:
+        loss_g, _ = graphed(batch)
+        negatives = graphed.steps[batch[1]].last_negatives.clone()
+        task._static_negative = negatives
+        loss_e, _ = engine.train_step(task, opt_e, batch)
+        task._static_negative = None
+        assert loss_g.item() == loss_e.item(), batch[1]
+    assert set(graphed.steps) == set(PRETRAIN_3G)
+    for (k, a), (_, b) in zip(task.named_parameters(), twin.named_parameters()):
+        assert torch.equal(a, b), k

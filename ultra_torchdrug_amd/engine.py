@@ -184,6 +184,9 @@ class GraphedTrainStep:
             if not self.reduce_in_graph:
                 self._capture(reduce=False)
             self.last_negatives = task.last_negatives       # (B, num_negative): rewritten by every replay
+            # the gradient tensors THIS graph writes (allocated in its pool during the capture): several captured steps
+            # over one set of parameters (GraphedMultiGraphTrainStep) re-bind theirs before the optimizer step
+            self._grads = [(p, p.grad) for p in task.parameters() if p.grad is not None]
         finally:
             model.check_indices = True
 
@@ -236,6 +239,8 @@ class GraphedTrainStep:
         """One step on ``batch`` (same shape as the example): returns ``(loss, metrics averaged over ranks)``."""
         assert batch.shape == self.static_batch.shape
         self.static_batch.copy_(batch)
+        for p, grad in self._grads:
+            p.grad = grad
         if self.reducer is not None and not self.reduce_in_graph:
             with self.reducer.paused():             # (replays fire no hooks; this keeps it so by construction)
                 self.graph.replay()
@@ -246,6 +251,31 @@ class GraphedTrainStep:
                 allreduce_gradients(self.task)
         self.optimizer.step()
         return self.static_loss.detach(), reduce_metrics(self.static_metric)
+
+
+class GraphedMultiGraphTrainStep:
+    """Multi-graph pre-training (``ultra/engine.py:23-92``, ``task.py:637-890``) with one captured step PER GRAPH CONTEXT:
+    a batch ``(triples, graph_id)`` replays the :class:`GraphedTrainStep` of its graph (captured on first use), all of
+    them over the same parameters and optimizer -- each capture owns the gradient tensors its backward writes and
+    re-binds them to the parameters before the optimizer step.  The eager step of this workload is ~800 launches whose
+    host-side issue cost exceeds their GPU time; every rank may be on another graph in the same step, and the gradient
+    all-reduce (``reducer`` / flat) still follows each replay, so the sequence of collectives is the same on all ranks."""
+
+    def __init__(self, task, optimizer, batch_size, reducer=None, warmup=3):
+        self.task, self.optimizer, self.batch_size, self.reducer, self.warmup = task, optimizer, int(batch_size), reducer, warmup
+        self.steps = {}
+
+    def __call__(self, batch):
+        triples, graph_id = batch
+        graph_id = str(graph_id)
+        self.task.use(graph_id)
+        if len(triples) != self.batch_size:             # ragged batch: the eager step
+            return train_step(self.task, self.optimizer, (triples, graph_id), reducer=self.reducer)
+        step = self.steps.get(graph_id)
+        if step is None:
+            step = self.steps[graph_id] = GraphedTrainStep(self.task, self.optimizer, triples, warmup=self.warmup,
+                                                           reducer=self.reducer)
+        return step(triples)
 
 
 class GraphedScores:
