@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -1146,8 +1147,6 @@ int launch_rowgroup(RowGroupParams &q, bool backward, int sum_op, int mul_op, bo
 
 bool g_no_rowgroup = false;
 bool g_no_concurrent_tiles = false;
-constexpr unsigned long long kConcurrentSliceBytes = 2560ull * 1024;      // slices of concurrently processed tiles per XCD
-constexpr bool TWO_GATHERS_KIND(int kind) { return kind == KIND_DREL; }
 
 // Runs one plan: segment_kernel over the chunk schedule, then fixup_kernel over the split rows.
 template <int KIND>
@@ -1309,15 +1308,20 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
                               (p.bnode == nullptr || p.bdim % 4 == 0);
             if (quad) {
                 // tiles of one label side by side (quad.inc): as many as the label has, while every team keeps >= 4
-                // workgroups and the tiles' slices of the gathered matrix (LDS-resident with var 1) fit the XCD's 4 MB L2
-                // together with the streams around them
+                // workgroups.  Measured on every shape tried (rocprofv3, F = 1 024 / 2 048): S-codexs 28.8 -> 19.7 us,
+                // S-wn18rr 64.5 -> 60.6 / 172 -> 154 us, S-codexm 84.4 -> 80.8 us, S-fb15k237 246 -> 219 us -- also where
+                // the tiles' slices of the gathered matrix together exceed the XCD's 4 MB L2 (S-fb15k237: 4 x 3.7 MB): what
+                // the sequential walk gains in L2 hits it loses in per-tile start-up and tails; the Infinity Cache backs
+                // the gathers either way.
                 const int slots_per_label = (q.n_slots + kXcd - 1) / kXcd;
-                const unsigned long long slice = (var == 1) ? 0ull : (unsigned long long)gather_rows * kTile * 4ull +
-                                                                     (TWO_GATHERS_KIND(KIND) ? (unsigned long long)gather2_rows * kTile * 4ull : 0ull);
                 int conc = 1;
                 while (!g_no_concurrent_tiles && conc * 2 <= slots_per_label && blocks_per_label % (conc * 2) == 0 &&
-                       blocks_per_label / (conc * 2) >= 4 && (unsigned long long)(conc * 2) * slice <= kConcurrentSliceBytes)
+                       blocks_per_label / (conc * 2) >= 4)
                     conc *= 2;
+                if (const char *force = getenv("ULTRA_CONC")) {      // experiments: force the number of concurrent tiles
+                    const int want = atoi(force);
+                    if (want >= 1 && blocks_per_label % want == 0) conc = want;
+                }
                 q.concurrent = conc;
                 rc = launch_quad<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var == 1, grid, kLdsHeader + lds_bytes, stream);
             }
