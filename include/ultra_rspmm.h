@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_RSPMM_ABI_VERSION 4
+#define ULTRA_RSPMM_ABI_VERSION 5
 
 /* sum= / mul= of generalized_rspmm (layer.py:134-167: sum in {"add","max","min"}, mul in {"mul","add"}) */
 enum ultra_sum_op { ULTRA_SUM_ADD = 0, ULTRA_SUM_MIN = 1, ULTRA_SUM_MAX = 2 };
@@ -287,11 +287,15 @@ int ultra_linear_forward_f32(const float *input, const float *weight, const floa
  * Score head of full-batch evaluation, fused:  out[b, n] = w2 . relu(W1 . cat[hidden[n, b, :], query[b, :]] + b1) + b2
  * replaces cat (/root/reference/ultra/model.py:134-138), transpose + gather of all candidate tails (:177-183, the
  * identity permutation when every entity is a candidate: ultra/task.py:249-253) and the 128 -> 128 -> 1 mlp (:193).
- * hidden [n_node, batch, 64], query [batch, 64], w1 [128, 128], b1 [128], w2 [128], b2 [1], out [batch, n_node].
- * Same summation order as ultra_linear_forward_f32 (128, 128, relu) followed by (128, 1): bit-identical results.
+ * hidden [n_node, batch, 64], query [batch, 64], w1 [128, 128], b1 [128], w2 [128], b2 [1], out [batch, n_node];
+ * query_bias [batch, 128]: scratch the call fills with the queries' share of the first layer,
+ *     c[b, o] = b1[o] + w1[o, 64:] . query[b]                     (fmaf chain k = 64, 96, 65, 97, ... from the bias)
+ *     h[o]    = relu(c[b, o] + w1[o, :64] . hidden[n, b])          (chain k = 0, 32, 1, 33, ... from c)
+ *     out     = b2 + sum_o h[o] w2[o]                              (o ascending)
+ * -- the order oracle/rspmm_oracle.c restates (ABI 5; up to ABI 4 the 128-wide product ran per row).
  */
 int ultra_score_forward_f32(const float *hidden, const float *query, const float *w1, const float *b1, const float *w2,
-                            const float *b2, float *out, int64_t n_node, int64_t batch, void *stream);
+                            const float *b2, float *query_bias, float *out, int64_t n_node, int64_t batch, void *stream);
 
 /* The relation projections of all entity layers in one launch:
  *     out[l][r, b, :] = w2[l] . relu( w1[l] . relation[b, r, :] + b1[l] ) + b2[l]

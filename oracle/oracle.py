@@ -42,7 +42,7 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_abi_version.restype = ctypes.c_int
         for name in ("oracle_rspmm_forward", "oracle_rspmm_backward", "oracle_filtered_rank", "oracle_combine_forward",
-                     "oracle_linear_forward"):
+                     "oracle_linear_forward", "oracle_linear_forward_grouped"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -253,3 +253,28 @@ def linear_forward(input, weight, bias, relu=False):
     if rc:
         raise RuntimeError("oracle_linear_forward failed")
     return out.reshape(lead + (out_dim,))
+
+
+def score_head_forward(hidden, query, w1, b1, w2, b2):
+    """Score head of full-batch evaluation (``ultra/model.py:134-138,177-193``: ``mlp(cat[hidden, query])`` for every
+    entity as candidate) in the kernels' documented order: ``hidden`` ``(N, B, 64)``, ``query`` ``(B, 64)`` -> ``(B, N)``.
+    The query half of the 128-wide first layer is summed once per query (``c = b1 + W1[:, 64:] . query``, a linear layer
+    over the B queries) and is the starting value of the hidden half's chain (``oracle_linear_forward_grouped``)."""
+    hidden = np.ascontiguousarray(hidden, dtype=np.float32)
+    query = np.ascontiguousarray(query, dtype=np.float32)
+    w1 = np.ascontiguousarray(w1, dtype=np.float32)
+    n_node, batch, dim = hidden.shape
+    assert dim == 64 and query.shape == (batch, 64) and w1.shape == (128, 128)
+    c = np.empty((batch, 128), dtype=np.float32)
+    b1 = np.ascontiguousarray(b1, dtype=np.float32)
+    w_query = w1[:, 64:]                                            # a view: rows 128 floats apart
+    rc = lib().oracle_linear_forward_grouped(ctypes.c_void_p(query.ctypes.data), ctypes.c_void_p(w_query.ctypes.data),
+                                             _i64(128), _p(b1), _i64(max(batch, 1)), _p(c), _i64(batch), _i64(64),
+                                             _i64(128), 0)
+    rows = np.ascontiguousarray(hidden.transpose(1, 0, 2)).reshape(batch * n_node, 64)          # (B, N, 64): query-major
+    h = np.empty((batch * n_node, 128), dtype=np.float32)
+    rc |= lib().oracle_linear_forward_grouped(_p(rows), _p(w1), _i64(128), _p(c), _i64(max(n_node, 1)), _p(h),
+                                              _i64(batch * n_node), _i64(64), _i64(128), 1)
+    if rc:
+        raise RuntimeError("oracle_linear_forward_grouped failed")
+    return linear_forward(h, np.asarray(w2, dtype=np.float32).reshape(1, 128), b2).reshape(batch, n_node)

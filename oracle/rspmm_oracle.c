@@ -413,14 +413,31 @@ int oracle_combine_forward(const float *input, const float *update, const float 
  *   out_dim > 1 : acc = bias[o]; for s in 0..K/2-1: acc = fmaf(in[s], W[o][s], acc); acc = fmaf(in[K/2+s], W[o][K/2+s], acc)
  *   out_dim == 1: acc = bias[0]; for k ascending: acc = fmaf(in[k], W[0][k], acc)
  */
+int oracle_linear_forward_grouped(const float *input, const float *weight, int64_t weight_stride, const float *bias,
+                                  int64_t rows_per_bias, float *out, int64_t rows, int64_t in_dim, int64_t out_dim, int relu);
+
 int oracle_linear_forward(const float *input, const float *weight, const float *bias, float *out, int64_t rows,
                           int64_t in_dim, int64_t out_dim, int relu) {
+    return oracle_linear_forward_grouped(input, weight, in_dim, bias, rows > 0 ? rows : 1, out, rows, in_dim, out_dim, relu);
+}
+
+/*
+ * The same chains with (i) weight rows `weight_stride` floats apart (a column slice of a wider matrix) and (ii) one bias
+ * row per GROUP of `rows_per_bias` consecutive input rows: bias[(r / rows_per_bias) * out_dim + o].  The score head of
+ * full-batch evaluation (ultra/model.py:134-138,193) in the HIP library's order: the query half of cat[hidden, query]
+ * is one of B vectors, so c[b] = b1 + W1[:, 64:] . query[b] is a linear layer over the B queries and
+ * relu(c[b] + W1[:, :64] . hidden[n, b]) a linear layer over the rows of query b with c[b] as its bias.
+ */
+int oracle_linear_forward_grouped(const float *input, const float *weight, int64_t weight_stride, const float *bias,
+                                  int64_t rows_per_bias, float *out, int64_t rows, int64_t in_dim, int64_t out_dim, int relu) {
+    if (rows_per_bias <= 0 || weight_stride < in_dim) return 1;
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < rows; ++r) {
         const float *in = input + r * in_dim;
+        const float *brow = bias + (r / rows_per_bias) * out_dim;
         for (int64_t o = 0; o < out_dim; ++o) {
-            const float *w = weight + o * in_dim;
-            float acc = bias[o];
+            const float *w = weight + o * weight_stride;
+            float acc = brow[o];
             if (out_dim == 1) {
                 for (int64_t k = 0; k < in_dim; ++k) acc = fmaf(in[k], w[k], acc);
             } else {

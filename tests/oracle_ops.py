@@ -77,12 +77,11 @@ class OracleFunctional:
         return torch.from_numpy(out)
 
     def score_all_entities(self, hidden, query, w1, b1, w2, b2):
-        """(N, B, 64), (B, 64) -> (B, N): the reference's cat / transpose / mlp chain (model.py:134-138,177-193),
-        each nn.Linear in the documented order."""
-        n_node, batch, _ = hidden.shape
-        feature = torch.cat([hidden, query.expand(n_node, -1, -1)], dim=-1).transpose(0, 1)      # (B, N, 128)
-        h = self.linear_forward(feature.contiguous(), w1, b1, relu=True)
-        return self.linear_forward(h, w2, b2, relu=False).squeeze(-1)
+        """(N, B, 64), (B, 64) -> (B, N): the reference's cat / transpose / mlp chain (model.py:134-138,177-193) in the
+        documented order (the queries' half of the first layer once per query: oracle.score_head_forward)."""
+        out = O.score_head_forward(hidden.detach().numpy(), query.detach().numpy(), w1.detach().numpy(), b1.detach().numpy(),
+                                   w2.detach().numpy(), b2.detach().numpy())
+        return torch.from_numpy(out)
 
     def generalized_rspmm(self, sparse, relation, input, sum="add", mul="mul"):
         piece = sparse.piece_len if self.piece is None else self.piece       # None: each plan's own piece length

@@ -210,22 +210,26 @@ def test_inductive_zero_shot_inference_matches_oracle_path():
     assert torch.equal(rank_gpu.cpu()[safe], rank_cpu[safe]) and safe.float().mean() > 0.8
 
 
-def test_fused_score_head_equals_unfused_path():
-    """ultra_score_forward_f32 vs cat + gather + linear(128,128,relu) + linear(128,1) of the same library."""
+def test_fused_score_head_equals_the_oracle_order_and_torch():
+    """ultra_score_forward_f32 (the queries' half of the first layer once per query, then a 64-wide product per row)
+    bit for bit against the oracle's restatement of that order, and within fp32 tolerance of cat + mlp as the reference
+    writes it (ultra/model.py:134-138,193).  Batches of 32 / 64 / 70 queries: the per-query sums in LDS and from memory."""
     from ultra_torchdrug_amd import functional as UF
+    from oracle import oracle as O
     dev = torch.device("cuda:0")
     gen = torch.Generator(device="cpu").manual_seed(5)
-    for n_node, batch in [(1, 1), (37, 3), (1000, 16), (14541, 16)]:
-        hidden = torch.randn(n_node, batch, 64, generator=gen).to(dev)
-        query = torch.randn(batch, 64, generator=gen).to(dev)
-        l1, l2 = torch.nn.Linear(128, 128).to(dev), torch.nn.Linear(128, 1).to(dev)
+    for n_node, batch in [(1, 1), (37, 3), (1000, 16), (14541, 16), (200, 32), (150, 64), (100, 70), (33, 31)]:
+        hidden = torch.randn(n_node, batch, 64, generator=gen)
+        query = torch.randn(batch, 64, generator=gen)
+        l1, l2 = torch.nn.Linear(128, 128), torch.nn.Linear(128, 1)
         with torch.no_grad():
-            fused = UF.score_all_entities(hidden, query, l1.weight, l1.bias, l2.weight, l2.bias)
-            feature = torch.cat([hidden, query.expand(n_node, -1, -1)], dim=-1).transpose(0, 1).contiguous()
-            h = UF.linear_forward(feature, l1.weight, l1.bias, relu=True)
-            plain = UF.linear_forward(h, l2.weight, l2.bias).squeeze(-1)
+            expect = torch.from_numpy(O.score_head_forward(hidden.numpy(), query.numpy(), l1.weight.numpy(), l1.bias.numpy(),
+                                                           l2.weight.numpy(), l2.bias.numpy()))
+            feature = torch.cat([hidden, query.expand(n_node, -1, -1)], dim=-1).transpose(0, 1)
             ref = l2(torch.relu(l1(feature))).squeeze(-1)
-        assert torch.equal(fused, plain)
+            l1, l2 = l1.to(dev), l2.to(dev)
+            fused = UF.score_all_entities(hidden.to(dev), query.to(dev), l1.weight, l1.bias, l2.weight, l2.bias).cpu()
+        assert torch.equal(fused, expect), (n_node, batch, (fused - expect).abs().max().item())
         torch.testing.assert_close(fused, ref, rtol=2e-5, atol=2e-5)
 
 
@@ -486,3 +490,15 @@ def test_fused_inference_sequence_equals_the_layer_by_layer_path():
             got = UF.combine_forward(None, update, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, shortcut,
                                      input_boundary=(node, query))
             assert torch.equal(got, want)
+        # every form of the kernel: few / many tiles per wave (prefetching form from 4 096 tiles on), tables in LDS (up to 128
+        # queries) or read from memory, query counts below, at and above the 32 rows of a tile
+        for n_row, n_q in [(7, 1), (50, 3), (300, 31), (64, 40), (33, 128), (20, 130), (5000, 32), (1100, 130), (45000, 3)]:
+            node = torch.randint(0, n_row, (n_q,), generator=gen).to(torch.int32).to(dev)
+            value = torch.randn(n_q, 64, generator=gen).to(dev)
+            update = torch.randn(n_row, n_q, 64, generator=gen).to(dev)
+            dense = torch.zeros(n_row, n_q, 64, device=dev)
+            dense[node.long(), torch.arange(n_q, device=dev)] = value
+            want = UF.combine_forward(dense, update, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, True)
+            got = UF.combine_forward(None, update, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, True, True,
+                                     input_boundary=(node, value))
+            assert torch.equal(got, want), (n_row, n_q)

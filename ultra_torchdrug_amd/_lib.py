@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ULTRA_RSPMM_LIB: load another build of the same ABI (kernel A/B runs, tools/kbench.py)
 LIB_PATH = os.environ.get("ULTRA_RSPMM_LIB") or os.path.join(_HERE, "libultra_rspmm.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SUM_OPS = {"add": 0, "min": 1, "max": 2}
 MUL_OPS = {"mul": 0, "add": 1}
@@ -161,7 +161,7 @@ def load():
     lib.ultra_linear_forward_f32.restype = i32
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.ultra_score_forward_f32.restype = i32
-    lib.ultra_score_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    lib.ultra_score_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
     lib.ultra_relation_project_f32.restype = i32
     lib.ultra_relation_project_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]
     lib.ultra_relation_project_backward_blocks.restype = i32

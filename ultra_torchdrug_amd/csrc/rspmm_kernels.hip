@@ -661,6 +661,7 @@ constexpr int kCbRows = 32;
 constexpr int kCbStride = 132;                 // 128 floats + 4 pad
 constexpr int kCbWaves = 4;                    // waves per workgroup
 constexpr int kCbTileFloats = kCbRows * kCbStride;
+constexpr int kCbLdsQueries = 128;             // boundary form: up to this many queries keep node + value in LDS
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -688,7 +689,11 @@ struct CombineParams {
 // before the GEMM of the current tile and land while the matrix cores run -- with two waves per SIMD and no prefetch
 // the waves fall into step (both wait for HBM, then both want the MFMA pipe: 37 % MFMA busy, PMC).  PF = false: the
 // two-waves-per-SIMD form, for inputs of a few tiles per wave.
-template <bool PF>
+// BND: the first layer's form -- `input` is the boundary, synthesised from (in_bnode, in_bvec): 1 = both staged in LDS
+// (up to kCbLdsQueries queries), 2 = read from memory (any number; the dependent loads make the prefetch synchronous).
+// Template parameters, not run-time branches in `fetch`: a branch that MAY load makes the compiler wait for every load
+// in flight at its join (vmcnt is in order) -- 129 vs 94 us -- and cost the common form registers (100 -> 145 us).
+template <bool PF, int BND = 0>
 __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(const CombineParams p) {
     extern __shared__ __attribute__((aligned(16))) float cb_lds[];
     const int lane = threadIdx.x & 63;
@@ -714,23 +719,46 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
     // gamma | beta in LDS behind the tiles (a global load per element inside the row loop costs more than the GEMM)
     float *gb = cb_lds + kCbWaves * kCbTileFloats;
     if (p.gamma != nullptr && threadIdx.x < 128) gb[threadIdx.x] = threadIdx.x < 64 ? p.gamma[threadIdx.x] : p.beta[threadIdx.x - 64];
+    // boundary form: the queries' nodes behind that (LDS reads in `fetch` wait on lgkmcnt; as global loads they sat in
+    // front of the row loads in the in-order vmcnt queue and made the prefetch synchronous: 140 vs 101 us)
+    float *bv_lds = gb + 128;                                       // [rpn][64] the queries' boundary values
+    int *bn_lds = reinterpret_cast<int *>(bv_lds + (size_t)p.rpn * 64);   // [rpn] their nodes
+    if constexpr (BND == 1) {
+        for (int j = threadIdx.x; j < p.rpn; j += kCbWaves * 64) bn_lds[j] = p.in_bnode[j];
+        for (int j = threadIdx.x; j < p.rpn * 16; j += kCbWaves * 64)
+            reinterpret_cast<f32x4 *>(bv_lds)[j] = reinterpret_cast<const f32x4 *>(p.in_bvec)[j];
+    }
     __syncthreads();
 
     const long long last = p.rows - 1;
     f32x4 pa[8], pb[8];     // PF: the staged rows of the tile about to be processed
     auto fetch = [&](long long t) {
+        // boundary form: (node, query) of the tile's first row once per tile, on the scalar unit (t is wave-uniform); a
+        // 64-bit division per fetched row cost 37 us of this kernel's 140 on the headline batch
+        long long node0 = 0;
+        int query0 = 0;
+        if constexpr (BND != 0) {
+            node0 = (t * kCbRows) / p.rpn;
+            query0 = (int)(t * kCbRows - node0 * p.rpn);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
             long long gr = t * kCbRows + r;
             gr = gr < last ? gr : last;
-            if (p.in_bnode == nullptr) {
+            if constexpr (BND == 0) {
                 pa[q] = *reinterpret_cast<const f32x4 *>(p.input + gr * 64 + c);
             } else {                 // row (node, query) of the boundary: the query's value at its own node, +0 elsewhere
-                const long long node = gr / p.rpn;
-                const int query = (int)(gr - node * p.rpn);
+                const unsigned qq = (unsigned)(query0 + r);              // < rpn + 32
+                const unsigned step = p.rpn >= kCbRows ? (qq >= (unsigned)p.rpn ? 1u : 0u) : qq / (unsigned)p.rpn;
+                const int query = (int)(qq - step * (unsigned)p.rpn);
                 const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-                pa[q] = ((int)node == p.in_bnode[query]) ? *reinterpret_cast<const f32x4 *>(p.in_bvec + query * 64 + c) : zero;
+                if constexpr (BND == 1) {     // LDS reads + select: nothing here touches vmcnt
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(bv_lds + query * 64 + c);
+                    pa[q] = (node0 + step == (long long)bn_lds[query]) ? v : zero;
+                } else {
+                    pa[q] = (node0 + step == (long long)p.in_bnode[query]) ? *reinterpret_cast<const f32x4 *>(p.in_bvec + query * 64 + c) : zero;
+                }
             }
             pb[q] = *reinterpret_cast<const f32x4 *>(p.update + gr * 64 + c);
         }
@@ -1667,19 +1695,36 @@ static int combine_launch(const CombineParams &p, void *stream) {
     const bool prefetch = n_tiles >= (long long)di->n_cu * kCbWaves * 4;
     const long long resident = (long long)di->n_cu * (prefetch ? 1 : 2);
     if (blocks > resident) blocks = resident;
-    const size_t lds = (size_t)(kCbWaves * kCbTileFloats + 128) * sizeof(float);
+    const size_t lds_max = (size_t)(kCbWaves * kCbTileFloats + 128 + kCbLdsQueries * 65) * sizeof(float);
+    const size_t lds = (size_t)(kCbWaves * kCbTileFloats + 128 + (p.in_bnode != nullptr && p.rpn <= kCbLdsQueries ? p.rpn * 65 : 0)) * sizeof(float);
     static bool attr_set[16] = {false};
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<false, 0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<true, 0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<false, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<true, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<false, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<true, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_set[dev] = true;
     }
-    if (prefetch)
-        hipLaunchKernelGGL(combine_kernel<true>, dim3((unsigned)blocks), dim3(kCbWaves * 64), lds, static_cast<hipStream_t>(stream), p);
-    else
-        hipLaunchKernelGGL(combine_kernel<false>, dim3((unsigned)blocks), dim3(kCbWaves * 64), lds, static_cast<hipStream_t>(stream), p);
+    const dim3 grid((unsigned)blocks), block(kCbWaves * 64);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p.in_bnode != nullptr && p.rpn <= kCbLdsQueries) {
+        if (prefetch) hipLaunchKernelGGL((combine_kernel<true, 1>), grid, block, lds, st, p);
+        else hipLaunchKernelGGL((combine_kernel<false, 1>), grid, block, lds, st, p);
+    } else if (p.in_bnode != nullptr) {
+        if (prefetch) hipLaunchKernelGGL((combine_kernel<true, 2>), grid, block, lds, st, p);
+        else hipLaunchKernelGGL((combine_kernel<false, 2>), grid, block, lds, st, p);
+    } else {
+        if (prefetch) hipLaunchKernelGGL((combine_kernel<true, 0>), grid, block, lds, st, p);
+        else hipLaunchKernelGGL((combine_kernel<false, 0>), grid, block, lds, st, p);
+    }
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
 }

@@ -346,12 +346,13 @@ def score_all_entities(hidden, query, w1, b1, w2, b2):
     if any(t.dtype != torch.float32 or not t.is_cuda or t.device != hidden.device for t in tensors):
         raise RuntimeError("score_all_entities needs fp32 tensors on one HIP device (no CPU fallback)")
     out = torch.empty(batch, n_node, dtype=torch.float32, device=hidden.device)
+    query_bias = torch.empty(batch, 128, dtype=torch.float32, device=hidden.device)     # the queries' share of layer 1
     lib = _lib.load()
     with torch.cuda.device(hidden.device):
         _lib.check(lib.ultra_score_forward_f32(hidden.contiguous().data_ptr(), query.contiguous().data_ptr(),
                                                w1.contiguous().data_ptr(), b1.contiguous().data_ptr(),
-                                               w2.contiguous().data_ptr(), b2.contiguous().data_ptr(), out.data_ptr(),
-                                               n_node, batch, _stream()))
+                                               w2.contiguous().data_ptr(), b2.contiguous().data_ptr(),
+                                               query_bias.data_ptr(), out.data_ptr(), n_node, batch, _stream()))
     return out
 
 
