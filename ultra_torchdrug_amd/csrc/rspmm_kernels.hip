@@ -859,12 +859,19 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-        // ---- coalesced store of the finished 32 x 64 tile (8 KiB contiguous in `out`)
+        // ---- coalesced store of the finished 32 x 64 tile (8 KiB contiguous in `out`).  Buffer stores over a descriptor of
+        // exactly the tile's valid rows: rows past the end are dropped by the bounds check, so every store is issued
+        // UNCONDITIONALLY.  Behind `if (row < rows)` branches the compiler cannot know how many stores are in flight at
+        // the top of the loop (stores count in vmcnt on gfx9) and waited with vmcnt(0) for the prefetched rows -- i.e. for
+        // the write acknowledgements of the tile just stored, every iteration.
+        const long long left = p.rows - row0;
+        const __amdgpu_buffer_rsrc_t rsrc_tile = __builtin_amdgcn_make_buffer_rsrc(
+            p.out + row0 * 64, 0, (int)(left < kCbRows ? left : kCbRows) * 256, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
             const f32x4 d = *reinterpret_cast<const f32x4 *>(tile + r * kCbStride + 64 + c);
-            if (row0 + r < p.rows) *reinterpret_cast<f32x4 *>(p.out + (row0 + r) * 64 + c) = d;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(qu4, d), rsrc_tile, r * 256 + c * 4, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile is rewritten by the next iteration
     }

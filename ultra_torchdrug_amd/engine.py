@@ -143,7 +143,8 @@ class GraphedTrainStep:
       drops back to the default with a warning.  On the runtime this was developed on (PyTorch 2.10 + ROCm 7.0, RCCL
       2.26, one-rank group) the verification fails -- a captured all-reduce alone replays correctly, the captured step
       with bucket traffic does not (``tools/debug/graph_collective_probe.py``, ``graphed_reducer_diag2.py``; DESIGN.md
-      section 6) -- so the flag is opt-in and the overlap under replay remains unproven there.
+      section 6), and once in a while the verification's replay ends the process with a HIP abort -- so the flag is
+      opt-in, its test runs in a child process, and the overlap under replay remains unproven there.
     ``reduce_in_graph`` (attribute) tells which form is active."""
 
     def __init__(self, task, optimizer, example_batch, warmup=3, reducer=None, reduce_in_graph=False):
