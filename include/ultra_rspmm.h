@@ -301,14 +301,16 @@ int ultra_score_forward_f32(const float *hidden, const float *query, const float
  *     out[l][r, b, :] = w2[l] . relu( w1[l] . relation[b, r, :] + b1[l] ) + b2[l]
  * = `relation_projection` (2-layer MLP) of GeneralizedRelationalConvNBFMod followed by the (B, R, D) -> (R, B*D)
  * transpose (ultra/layer.py:228,318-319,325-326), which ultra/model.py:120-130 triggers once per layer.
- *   relation : fp32 [batch, n_rel, 64];  w1 / b1 / w2 / b2 / out : HOST arrays of n_layers DEVICE pointers
+ *   relation : fp32, row (b, r) = 64 floats at relation + stride_b * b + stride_r * r (contiguous [batch, n_rel, 64]:
+ *   n_rel * 64 and 64; the relation stack's own [n_rel, batch, 64] output: 64 and batch * 64; multiples of 4);
+ *   w1 / b1 / w2 / b2 / out : HOST arrays of n_layers DEVICE pointers
  *   (weights [64, 64] as nn.Linear.weight, biases [64], out[l] [n_rel, batch * repeat, 64]).  Bit-identical to two
  *   ultra_linear_forward_f32 calls + the transpose.  repeat >= 1: every projected row (b, r) is written to the query
  *   blocks b, b + batch, ...: the tables of `torch.cat([relation] * repeat)` (full-batch evaluation scores the tail and
  *   the head queries of a batch over the same relation representations, ultra/task.py:249-259) at the cost of one. */
-int ultra_relation_project_f32(const float *relation, const float *const *w1, const float *const *b1,
-                               const float *const *w2, const float *const *b2, float *const *out, int64_t n_layers,
-                               int64_t batch, int64_t repeat, int64_t n_rel, int64_t dim, void *stream);
+int ultra_relation_project_f32(const float *relation, int64_t stride_b, int64_t stride_r, const float *const *w1,
+                               const float *const *b1, const float *const *w2, const float *const *b2, float *const *out,
+                               int64_t n_layers, int64_t batch, int64_t repeat, int64_t n_rel, int64_t dim, void *stream);
 
 /* The index glue between the relation stack and the entity stack for one evaluation batch, in one launch: from the B
  * triples batch[b] = (h, t, r) (int64 [B, 3], the reference's column order, ultra/task.py:123) and the conditioned
@@ -317,9 +319,21 @@ int ultra_relation_project_f32(const float *relation, const float *const *w1, co
  *     q <  B : anchor = h[q],     relation = r[q]                    q >= B : anchor = t[q - B], relation = r[q - B] + n_base_rel
  *     query[q, :] = rel_rep[q mod B, relation[q], :]
  * Outputs: anchor int64 [2B], anchor32 int32 [2B], relation int64 [2B], query fp32 [2B, 64].  Plain copies: what the
- * reference's cat / add / arange / index kernels produce. */
-int ultra_prepare_queries(const int64_t *batch, const float *rel_rep, int64_t n_batch, int64_t n_rel2, int64_t n_base_rel,
-                          int64_t *anchor, int32_t *anchor32, int64_t *relation, float *query, void *stream);
+ * reference's cat / add / arange / index kernels produce.  rel_rep row (b, r) = 64 floats at stride_b * b + stride_r * r
+ * (as in ultra_relation_project_f32: the relation stack's [n_rel2, B, 64] output is read where it lies). */
+int ultra_prepare_queries(const int64_t *batch, const float *rel_rep, int64_t stride_b, int64_t stride_r, int64_t n_batch,
+                          int64_t n_rel2, int64_t n_base_rel, int64_t *anchor, int32_t *anchor32, int64_t *relation,
+                          float *query, void *stream);
+
+/* What the relation stack (RelNBFNet, /root/reference/ultra/rel_model.py:351-378) needs before its first layer, in one
+ * launch instead of stack / expand / ones / cast kernels:
+ *     tables[l, r, q, :] = weights[l][r, :]   the layers' relation embeddings (nn.Embedding(4, 64), ultra/layer.py:143-151)
+ *                                             tiled over the n_query query blocks: the (n_rel, n_query * 64) operand of rspmm
+ *     ones[q, :] = 1                          the boundary value of every query (rel_model.py:355)
+ *     node32[q] = (int32) h_index[q]          the boundary nodes (the batch's relations)
+ * weights: HOST array of n_layers (<= 8) DEVICE pointers, each [n_rel, 64]. */
+int ultra_relation_stack_inputs(const float *const *weights, int64_t n_layers, int64_t n_rel, int64_t n_query,
+                                const int64_t *h_index, float *tables, float *ones, int32_t *node32, void *stream);
 
 /* Backward of ultra_relation_project_f32 for all layers in one launch (training):
  *     d_w1[l], d_b1[l], d_w2[l], d_b2[l]   gradients of the layer's four parameters ([64, 64] / [64], overwritten)

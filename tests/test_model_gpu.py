@@ -494,6 +494,23 @@ def test_fused_inference_sequence_equals_the_layer_by_layer_path():
         once = UF.relation_project(rel_rep, weights, repeat=2)
         twice = UF.relation_project(torch.cat([rel_rep, rel_rep]), weights)
     assert all(torch.equal(a, b) for a, b in zip(once, twice))
+    # the relation stack's output is (2R, B, 64), handed on transposed (rel_model.py:378): both kernels read it where it lies
+    stacked = torch.randn(2 * R, B, 64, generator=gen).to(dev)
+    view = stacked.transpose(0, 1)
+    assert not view.is_contiguous() and UF._rows_in_place(view) is view
+    got = UF.prepare_queries(trip, view, R)
+    want = UF.prepare_queries(trip, view.contiguous(), R)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    with torch.no_grad():
+        assert all(torch.equal(a, b) for a, b in zip(UF.relation_project(view, weights, repeat=2),
+                                                     UF.relation_project(view.contiguous(), weights, repeat=2)))
+    # inputs of the relation stack's first layer in one launch
+    embeddings = [torch.randn(4, 64, generator=gen).to(dev) for _ in range(6)]
+    for n_q in (1, 5, 16, 33):
+        h_index = torch.randint(0, 2 * R, (n_q,), generator=gen).to(dev)
+        tables, ones, node32 = UF.relation_stack_inputs(embeddings, h_index)
+        assert torch.equal(tables, torch.stack(embeddings).unsqueeze(2).expand(-1, -1, n_q, -1).reshape(6, 4, n_q * 64))
+        assert torch.equal(ones, torch.ones(n_q, 64, device=dev)) and torch.equal(node32, h_index.to(torch.int32))
     n = 300
     node = torch.randint(0, n, (2 * B,), generator=gen).to(torch.int32).to(dev)
     node[3] = node[5]                                          # two queries starting at one node

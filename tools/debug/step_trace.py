@@ -9,7 +9,7 @@ from ultra_torchdrug_amd.engine import GraphedPredict
 from ultra_torchdrug_amd.data import DEFAULT_SEED
 
 dev = torch.device("cuda:0")
-task, triples, fact_mask, n_fact = bench.transductive_task("S-fb15k237", dev, 2048, DEFAULT_SEED)
+task, triples, fact_mask, n_fact = bench.transductive_task(os.environ.get("WORKLOAD", "S-fb15k237"), dev, 2048, DEFAULT_SEED)
 bench.prepare_plans(task)
 test = torch.from_numpy(triples[n_fact:]).to(dev)
 with torch.no_grad():

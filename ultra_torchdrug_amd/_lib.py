@@ -74,6 +74,7 @@ EXPORTS = (
     "ultra_strict_negative",
     "ultra_edge_removal_weights",
     "ultra_prepare_queries",
+    "ultra_relation_stack_inputs",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
     "ultra_relcsr_plan_temp_bytes",
@@ -146,7 +147,9 @@ def load():
     lib.ultra_combine_forward_boundary_f32.restype = i32
     lib.ultra_combine_forward_boundary_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, i64, vp]
     lib.ultra_prepare_queries.restype = i32
-    lib.ultra_prepare_queries.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.ultra_prepare_queries.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.ultra_relation_stack_inputs.restype = i32
+    lib.ultra_relation_stack_inputs.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
     lib.ultra_combine_backward_waves.restype = i32
     lib.ultra_combine_backward_waves.argtypes = [i32, i64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.ultra_combine_backward_f32.restype = i32
@@ -163,7 +166,7 @@ def load():
     lib.ultra_score_forward_f32.restype = i32
     lib.ultra_score_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
     lib.ultra_relation_project_f32.restype = i32
-    lib.ultra_relation_project_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]
+    lib.ultra_relation_project_f32.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]
     lib.ultra_relation_project_backward_blocks.restype = i32
     lib.ultra_relation_project_backward_blocks.argtypes = [i32, i64, i64, i64, vp]
     lib.ultra_relation_project_backward_f32.restype = i32

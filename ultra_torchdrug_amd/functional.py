@@ -21,7 +21,7 @@ import torch
 from . import _lib, _torch_ext
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -356,6 +356,41 @@ def score_all_entities(hidden, query, w1, b1, w2, b2):
     return out
 
 
+def _rows_in_place(t):
+    """``t`` ``(B, R, 64)`` as the kernels can read it without a copy: rows of 64 contiguous floats at 16-byte-aligned
+    strides (the relation stack returns its ``(R, B, 64)`` output transposed, ``ultra/rel_model.py:378``) -- else a
+    contiguous copy."""
+    if t.stride(2) == 1 and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous()
+
+
+def relation_stack_inputs(weights, h_index):
+    """Inputs of the relation stack's first layer in one launch (``ultra_relation_stack_inputs``): ``weights``: the layers'
+    relation embeddings, each fp32 ``(R4, 64)``; ``h_index`` int64 ``(Q,)``.  Returns ``(tables (L, R4, Q * 64), ones (Q, 64),
+    node32 int32 (Q,))`` -- ``stack(weights).unsqueeze(2).expand(-1, -1, Q, -1).reshape(L, R4, Q * 64)``, ``torch.ones(Q, 64)``
+    and ``h_index.to(int32)`` (``ultra/rel_model.py:351-378``, ``ultra/layer.py:143-151``)."""
+    import ctypes
+    n = len(weights)
+    keep = [w.detach().contiguous() for w in weights]
+    h_index = h_index.contiguous()
+    if (n == 0 or n > 8 or h_index.dtype != torch.int64 or h_index.dim() != 1 or not h_index.is_cuda
+            or any(w.dtype != torch.float32 or w.dim() != 2 or w.shape != keep[0].shape or w.shape[1] != 64 or w.device != h_index.device
+                   for w in keep)):
+        raise RuntimeError("relation_stack_inputs: 1..8 fp32 (R, 64) tables and int64 (Q,) indices on one HIP device")
+    n_rel, n_query, dev = keep[0].shape[0], h_index.shape[0], h_index.device
+    tables = torch.empty(n, n_rel, n_query * 64, dtype=torch.float32, device=dev)
+    ones = torch.empty(n_query, 64, dtype=torch.float32, device=dev)
+    node32 = torch.empty(n_query, dtype=torch.int32, device=dev)
+    if n_query:
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_relation_stack_inputs((ctypes.c_void_p * n)(*[w.data_ptr() for w in keep]), n, n_rel, n_query,
+                                                       h_index.data_ptr(), tables.data_ptr(), ones.data_ptr(), node32.data_ptr(),
+                                                       _stream()))
+    return tables, ones, node32
+
+
 def relation_project(relation, weights, repeat=1):
     """All layers' relation projections in one launch.  ``relation``: fp32 ``(B, R, 64)``; ``weights``: one
     ``(w1, b1, w2, b2)`` per layer (``nn.Linear`` weights ``(64, 64)`` / biases ``(64,)`` of the 2-layer
@@ -364,9 +399,9 @@ def relation_project(relation, weights, repeat=1):
     ``repeat``: the tables of ``torch.cat([relation] * repeat)`` -- ``(R, repeat * B * 64)``, query block ``b + j B`` a copy of
     block ``b`` -- computed once (full-batch evaluation: tail and head queries share the relation representations)."""
     import ctypes
-    relation = relation.contiguous()
     if relation.dim() != 3 or relation.shape[-1] != 64 or relation.dtype != torch.float32 or not relation.is_cuda:
         raise RuntimeError("relation_project: fp32 (B, R, 64) on a HIP device, got %s" % (tuple(relation.shape),))
+    relation = _rows_in_place(relation)
     batch, n_rel, _ = relation.shape
     n = len(weights)
     keep, cols = [], [[], [], [], []]
@@ -385,7 +420,7 @@ def relation_project(relation, weights, repeat=1):
     lib = _lib.load()
     with torch.cuda.device(relation.device):
         _lib.check(lib.ultra_relation_project_f32(
-            relation.data_ptr(), arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]),
+            relation.data_ptr(), relation.stride(0), relation.stride(1), arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]),
             arr([o.data_ptr() for o in outs]), n, batch, repeat, n_rel, 64, _stream()))
     return outs
 
@@ -447,12 +482,12 @@ def prepare_queries(batch, rel_rep, n_base_rel):
     ``cat([h, t])``, ``cat([r, r + R])`` and ``cat([rel_rep, rel_rep])[arange(2B), relation]`` give (task.py:249-259,
     model.py:76-83,101-105), nine index kernels of a few microseconds each otherwise."""
     batch = batch.contiguous()
-    rel_rep = rel_rep.contiguous()
     n_batch = batch.shape[0]
     if (batch.dtype != torch.int64 or batch.dim() != 2 or batch.shape[1] != 3 or not batch.is_cuda or rel_rep.dtype != torch.float32
             or rel_rep.dim() != 3 or rel_rep.shape[0] != n_batch or rel_rep.shape[2] != 64 or rel_rep.device != batch.device
             or 2 * int(n_base_rel) != rel_rep.shape[1]):
         raise RuntimeError("prepare_queries: batch int64 (B, 3) and rel_rep fp32 (B, 2 * n_base_rel, 64) on one HIP device")
+    rel_rep = _rows_in_place(rel_rep)
     dev = batch.device
     anchor = torch.empty(2 * n_batch, dtype=torch.int64, device=dev)
     anchor32 = torch.empty(2 * n_batch, dtype=torch.int32, device=dev)
@@ -461,7 +496,8 @@ def prepare_queries(batch, rel_rep, n_base_rel):
     if n_batch:
         lib = _lib.load()
         with torch.cuda.device(dev):
-            _lib.check(lib.ultra_prepare_queries(batch.data_ptr(), rel_rep.data_ptr(), n_batch, rel_rep.shape[1], int(n_base_rel),
+            _lib.check(lib.ultra_prepare_queries(batch.data_ptr(), rel_rep.data_ptr(), rel_rep.stride(0), rel_rep.stride(1), n_batch,
+                                                 rel_rep.shape[1], int(n_base_rel),
                                                  anchor.data_ptr(), anchor32.data_ptr(), relation.data_ptr(), query.data_ptr(),
                                                  _stream()))
     return anchor, anchor32, relation, query

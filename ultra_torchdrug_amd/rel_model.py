@@ -145,12 +145,12 @@ class CustomNBFNetFull(CustomNBFNet):
         # (nothing is cached across calls: a captured hipGraph holds raw pointers to every tensor it read, and a cache
         # rebuilt for another batch size -- or stale after a weight update -- would silently invalidate it)
         weights = [conv.relation.weight for conv in self.layers]
-        n_rel, dim = weights[0].shape
-        tables = torch.stack(weights).unsqueeze(2).expand(-1, -1, n_query, -1).reshape(len(weights), n_rel, n_query * dim)
+        if len(weights) > 8 or self.dims[0] != 64 or not n_query:
+            return None
+        tables, query, node32 = ops.relation_stack_inputs(weights, h_index)      # tiled tables, ones, int32 nodes: one launch
         if not layer._frontier_tables_finite(tables[0]):
             return None
-        query = torch.ones(n_query, self.dims[0], device=h_index.device)
-        boundary = (h_index.to(torch.int32), query)
+        boundary = (node32, query)
         csr = graph.relcsr
         n_node = graph.num_node
         hidden = None
