@@ -330,10 +330,12 @@ int ultra_prepare_queries(const int64_t *batch, const float *rel_rep, int64_t st
  *     tables[l, r, q, :] = weights[l][r, :]   the layers' relation embeddings (nn.Embedding(4, 64), ultra/layer.py:143-151)
  *                                             tiled over the n_query query blocks: the (n_rel, n_query * 64) operand of rspmm
  *     ones[q, :] = 1                          the boundary value of every query (rel_model.py:355)
- *     node32[q] = (int32) h_index[q]          the boundary nodes (the batch's relations)
+ *     node32[q] = (int32) h_index[q * h_stride]   the boundary nodes (the batch's relations: column 2 of the (B, 3)
+ *                                             batch is read in place with h_stride = 3)
  * weights: HOST array of n_layers (<= 8) DEVICE pointers, each [n_rel, 64]. */
 int ultra_relation_stack_inputs(const float *const *weights, int64_t n_layers, int64_t n_rel, int64_t n_query,
-                                const int64_t *h_index, float *tables, float *ones, int32_t *node32, void *stream);
+                                const int64_t *h_index, int64_t h_stride, float *tables, float *ones, int32_t *node32,
+                                void *stream);
 
 /* Backward of ultra_relation_project_f32 for all layers in one launch (training):
  *     d_w1[l], d_b1[l], d_w2[l], d_b2[l]   gradients of the layer's four parameters ([64, 64] / [64], overwritten)

@@ -511,6 +511,9 @@ def test_fused_inference_sequence_equals_the_layer_by_layer_path():
         tables, ones, node32 = UF.relation_stack_inputs(embeddings, h_index)
         assert torch.equal(tables, torch.stack(embeddings).unsqueeze(2).expand(-1, -1, n_q, -1).reshape(6, 4, n_q * 64))
         assert torch.equal(ones, torch.ones(n_q, 64, device=dev)) and torch.equal(node32, h_index.to(torch.int32))
+    column = trip[:, 2]                                         # a strided view: read in place
+    assert not column.is_contiguous()
+    assert torch.equal(UF.relation_stack_inputs(embeddings, column)[2], column.to(torch.int32))
     n = 300
     node = torch.randint(0, n, (2 * B,), generator=gen).to(torch.int32).to(dev)
     node[3] = node[5]                                          # two queries starting at one node

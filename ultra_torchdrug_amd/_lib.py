@@ -149,7 +149,7 @@ def load():
     lib.ultra_prepare_queries.restype = i32
     lib.ultra_prepare_queries.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp]
     lib.ultra_relation_stack_inputs.restype = i32
-    lib.ultra_relation_stack_inputs.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.ultra_relation_stack_inputs.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, vp, vp]
     lib.ultra_combine_backward_waves.restype = i32
     lib.ultra_combine_backward_waves.argtypes = [i32, i64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.ultra_combine_backward_f32.restype = i32

@@ -373,7 +373,6 @@ def relation_stack_inputs(weights, h_index):
     import ctypes
     n = len(weights)
     keep = [w.detach().contiguous() for w in weights]
-    h_index = h_index.contiguous()
     if (n == 0 or n > 8 or h_index.dtype != torch.int64 or h_index.dim() != 1 or not h_index.is_cuda
             or any(w.dtype != torch.float32 or w.dim() != 2 or w.shape != keep[0].shape or w.shape[1] != 64 or w.device != h_index.device
                    for w in keep)):
@@ -386,8 +385,8 @@ def relation_stack_inputs(weights, h_index):
         lib = _lib.load()
         with torch.cuda.device(dev):
             _lib.check(lib.ultra_relation_stack_inputs((ctypes.c_void_p * n)(*[w.data_ptr() for w in keep]), n, n_rel, n_query,
-                                                       h_index.data_ptr(), tables.data_ptr(), ones.data_ptr(), node32.data_ptr(),
-                                                       _stream()))
+                                                       h_index.data_ptr(), h_index.stride(0), tables.data_ptr(), ones.data_ptr(),
+                                                       node32.data_ptr(), _stream()))
     return tables, ones, node32
 
 
