@@ -337,6 +337,16 @@ int ultra_relation_stack_inputs(const float *const *weights, int64_t n_layers, i
                                 const int64_t *h_index, int64_t h_stride, float *tables, float *ones, int32_t *node32,
                                 void *stream);
 
+/* Training metrics: norm, mean and unbiased standard deviation of the values { a[0 .. n_a) } together with every b[0 .. n_b)
+ * taken b_repeat times, in two launches with double-precision accumulation:  out[0..2] = (norm, mean, std).
+ * The reference logs them in every training forward for the relation representations (`query_*`,
+ * /root/reference/ultra/model.py:158-160) and for node_feature = cat[hidden, query] (`output_*`, :178-181; the query half
+ * is B vectors repeated for every node: b, b_repeat = n_node, never materialised).  partials: scratch of
+ * 2 * ultra_statistics_blocks(n_a) doubles; a 16-byte aligned. */
+int ultra_statistics_blocks(int64_t n_a);
+int ultra_statistics_f32(const float *a, int64_t n_a, const float *b, int64_t n_b, int64_t b_repeat, double *partials,
+                         float *out, void *stream);
+
 /* Backward of ultra_relation_project_f32 for all layers in one launch (training):
  *     d_w1[l], d_b1[l], d_w2[l], d_b2[l]   gradients of the layer's four parameters ([64, 64] / [64], overwritten)
  *     d_relation_layers[l, b * n_rel + r, :]   the layer's gradient of relation[b, r, :]; the input feeds every layer,

@@ -83,6 +83,15 @@ class OracleFunctional:
                                    w2.detach().numpy(), b2.detach().numpy())
         return torch.from_numpy(out)
 
+    @staticmethod
+    def statistics(values, repeated=None, repeat=0):
+        """(norm, mean, std) of `values` with `repeated` taken `repeat` times, as the reference computes them: ATen
+        reductions over the materialised tensor (model.py:158-160,178-181)."""
+        flat = values.detach().reshape(-1)
+        if repeated is not None:
+            flat = torch.cat([flat, repeated.detach().reshape(1, -1).expand(int(repeat), -1).reshape(-1)])
+        return torch.stack([flat.norm(), flat.mean(), flat.std()])
+
     def generalized_rspmm(self, sparse, relation, input, sum="add", mul="mul"):
         piece = sparse.piece_len if self.piece is None else self.piece       # None: each plan's own piece length
         return _OracleRSPMM.apply(relation.contiguous(), input.contiguous(), self._csr(sparse), sum, mul, piece)

@@ -429,6 +429,41 @@ def test_gradient_reducer_over_rccl_single_rank_group():
         dist.destroy_process_group()
 
 
+def test_training_metric_statistics_equal_the_reference_formulas():
+    """ultra_statistics_f32 (two launches, double accumulation) against Tensor.norm / mean / std over the materialised tensor
+    in fp64, as the reference logs them (ultra/model.py:158-160 `query_*`, :178-181 `output_*` of cat[hidden, query])."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    for n in (1, 2, 3, 1031, 4096, 70001):
+        x = torch.randn(n, generator=gen)
+        got = UF.statistics(x.to(dev)).cpu()
+        want = torch.stack([x.double().norm(), x.double().mean(), x.double().std()]).float()
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6, equal_nan=True)
+    for shape in [(7, 3, 64), (513, 2, 64), (14541, 32, 64)]:
+        hidden = torch.randn(*shape, generator=gen).relu() + 0.1
+        query = torch.randn(shape[1], 64, generator=gen)
+        feature = torch.cat([hidden, query.expand(shape[0], -1, -1)], dim=-1).double()
+        got = UF.statistics(hidden.to(dev), query.to(dev), shape[0]).cpu()
+        want = torch.stack([feature.norm(), feature.mean(), feature.std()]).float()
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    # the keys a training forward logs: HIP path vs the oracle path (ATen formulas)
+    task, triples = _build("S-tiny")
+    task.num_negative = 16
+    batch = torch.from_numpy(triples[:8])
+    task.train()
+    torch.manual_seed(3)
+    with oracle_rspmm(None):
+        _, metric_cpu = task(batch)
+    task.to(dev)
+    torch.manual_seed(3)
+    _, metric_gpu = task(batch.to(dev))
+    keys = [k for k in metric_cpu if k.endswith(("_norm", "_mean", "_std"))]
+    assert len(keys) >= 6
+    for k in keys:
+        torch.testing.assert_close(metric_gpu[k].cpu().float(), metric_cpu[k].float(), rtol=2e-3, atol=1e-4), k
+
+
 def test_captured_collectives_in_a_child_process():
     """GraphedTrainStep(reduce_in_graph=True): the bucket all-reduces captured INSIDE the step's hipGraph (hooks live during
     the capture, side stream forked from the capturing stream), verified against eager gradients before use and abandoned

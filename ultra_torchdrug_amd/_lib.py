@@ -75,6 +75,8 @@ EXPORTS = (
     "ultra_edge_removal_weights",
     "ultra_prepare_queries",
     "ultra_relation_stack_inputs",
+    "ultra_statistics_blocks",
+    "ultra_statistics_f32",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
     "ultra_relcsr_plan_temp_bytes",
@@ -148,6 +150,10 @@ def load():
     lib.ultra_combine_forward_boundary_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, i64, vp]
     lib.ultra_prepare_queries.restype = i32
     lib.ultra_prepare_queries.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.ultra_statistics_blocks.restype = i32
+    lib.ultra_statistics_blocks.argtypes = [i64]
+    lib.ultra_statistics_f32.restype = i32
+    lib.ultra_statistics_f32.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp]
     lib.ultra_relation_stack_inputs.restype = i32
     lib.ultra_relation_stack_inputs.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, vp, vp]
     lib.ultra_combine_backward_waves.restype = i32

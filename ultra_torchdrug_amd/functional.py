@@ -21,7 +21,7 @@ import torch
 from . import _lib, _torch_ext
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -363,6 +363,25 @@ def _rows_in_place(t):
     if t.stride(2) == 1 and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0:
         return t
     return t.contiguous()
+
+
+def statistics(values, repeated=None, repeat=0):
+    """``(norm, mean, std)`` (``Tensor.norm() / .mean() / .std()``, unbiased) of all elements of ``values`` together with the
+    elements of ``repeated`` taken ``repeat`` times, as one fp32 ``(3,)`` tensor -- two launches, double accumulation
+    (``ultra_statistics_f32``).  The reference's training metrics ``query_*`` / ``output_*`` (``ultra/model.py:158-160,
+    178-181``); ``cat[hidden, query]`` is never built: ``statistics(hidden, query, n_node)``."""
+    a = values.detach().contiguous()
+    b = None if repeated is None else repeated.detach().contiguous()
+    if a.dtype != torch.float32 or not a.is_cuda or (b is not None and (b.dtype != torch.float32 or b.device != a.device)):
+        raise RuntimeError("statistics needs fp32 tensors on one HIP device (no CPU fallback)")
+    lib = _lib.load()
+    out = torch.empty(3, dtype=torch.float32, device=a.device)
+    partials = torch.empty(2 * lib.ultra_statistics_blocks(a.numel()), dtype=torch.float64, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.ultra_statistics_f32(a.data_ptr(), a.numel(), b.data_ptr() if b is not None else None,
+                                            b.numel() if b is not None else 0, int(repeat) if b is not None else 0,
+                                            partials.data_ptr(), out.data_ptr(), _stream()))
+    return out
 
 
 def relation_stack_inputs(weights, h_index):

@@ -278,7 +278,11 @@ class TransferNBFNet(nn.Module):
                 conv.relation = rel_query_list[0]
         if metric is not None:
             q = self.query.detach()
-            metric["query_norm"], metric["query_mean"], metric["query_std"] = q.norm(), q.mean(), q.std()
+            ops = backend.get()
+            if ops.accepts(q) and q.dtype == torch.float32:
+                metric["query_norm"], metric["query_mean"], metric["query_std"] = ops.statistics(q).unbind(0)
+            else:
+                metric["query_norm"], metric["query_mean"], metric["query_std"] = q.norm(), q.mean(), q.std()
 
         shape = h_index.shape
         if graph.num_relation:
@@ -341,6 +345,10 @@ class TransferNBFNet(nn.Module):
         memset, and a memset node does not replay reliably inside a captured training step (frontier
         paragraph)."""
         n_node = hidden.shape[0]
+        ops = backend.get()
+        if ops.accepts(hidden) and hidden.dtype == torch.float32 and query.dtype == torch.float32:
+            metric["output_norm"], metric["output_mean"], metric["output_std"] = ops.statistics(hidden, query, n_node).unbind(0)
+            return
         flat = hidden.float().reshape(-1)
         n_h = flat.numel()
         chunk = 16384
