@@ -347,6 +347,13 @@ int ultra_statistics_blocks(int64_t n_a);
 int ultra_statistics_f32(const float *a, int64_t n_a, const float *b, int64_t n_b, int64_t b_repeat, double *partials,
                          float *out, void *stream);
 
+/* The training criterion and its gradient in one launch (/root/reference/ultra/task.py:169-180: binary cross entropy with
+ * logits over (positive | K negatives), self-adversarial negative weights softmax(pred[:, 1:] / T) without gradient -- or
+ * 1 / K when temperature <= 0 --, weighted mean per row):  pred fp32 [rows, cols] with the positive in column 0;
+ * loss_rows [rows]; dpred [rows, cols] = d loss_rows[row] / d pred[row, col]. */
+int ultra_bce_adversarial_f32(const float *pred, int64_t rows, int64_t cols, float temperature, float *loss_rows,
+                              float *dpred, void *stream);
+
 /* Backward of ultra_relation_project_f32 for all layers in one launch (training):
  *     d_w1[l], d_b1[l], d_w2[l], d_b2[l]   gradients of the layer's four parameters ([64, 64] / [64], overwritten)
  *     d_relation_layers[l, b * n_rel + r, :]   the layer's gradient of relation[b, r, :]; the input feeds every layer,

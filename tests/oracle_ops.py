@@ -84,6 +84,20 @@ class OracleFunctional:
         return torch.from_numpy(out)
 
     @staticmethod
+    def bce_adversarial_loss(pred, temperature):
+        """task.py:169-180 as the reference writes it (ATen ops, autograd)."""
+        target = torch.zeros_like(pred)
+        target[:, 0] = 1
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, target, reduction="none")
+        neg_weight = torch.ones_like(pred)
+        if temperature > 0:
+            with torch.no_grad():
+                neg_weight[:, 1:] = torch.nn.functional.softmax(pred[:, 1:] / temperature, dim=-1)
+        else:
+            neg_weight[:, 1:] = 1 / (pred.shape[1] - 1)
+        return (loss * neg_weight).sum(dim=-1) / neg_weight.sum(dim=-1)
+
+    @staticmethod
     def statistics(values, repeated=None, repeat=0):
         """(norm, mean, std) of `values` with `repeated` taken `repeat` times, as the reference computes them: ATen
         reductions over the materialised tensor (model.py:158-160,178-181)."""

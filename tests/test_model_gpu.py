@@ -464,6 +464,26 @@ def test_training_metric_statistics_equal_the_reference_formulas():
         torch.testing.assert_close(metric_gpu[k].cpu().float(), metric_cpu[k].float(), rtol=2e-3, atol=1e-4), k
 
 
+def test_fused_training_loss_equals_the_reference_chain():
+    """ultra_bce_adversarial_f32 (loss rows + gradient in one launch) against the ATen chain of ultra/task.py:169-180 in
+    fp64: binary_cross_entropy_with_logits, self-adversarial softmax weights without gradient, weighted mean per row."""
+    from ultra_torchdrug_amd import functional as UF
+    from oracle_ops import OracleFunctional as OracleOps
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(21)
+    for rows, negatives, temperature in [(1, 1, 1.0), (16, 128, 1.0), (16, 128, 0.5), (7, 1000, 2.0), (5, 33, 0.0), (64, 256, 1.0)]:
+        pred = (4 * torch.randn(rows, 1 + negatives, generator=gen))
+        a = pred.clone().to(dev).requires_grad_()
+        b = pred.clone().double().requires_grad_()
+        upstream = torch.rand(rows, generator=gen)
+        got = UF.bce_adversarial_loss(a, temperature)
+        want = OracleOps.bce_adversarial_loss(b, temperature)
+        got.backward(upstream.to(dev))
+        want.backward(upstream.double())
+        torch.testing.assert_close(got.detach().cpu(), want.detach().float(), rtol=2e-6, atol=2e-6)
+        torch.testing.assert_close(a.grad.cpu(), b.grad.float(), rtol=1e-5, atol=1e-7)
+
+
 def test_captured_collectives_in_a_child_process():
     """GraphedTrainStep(reduce_in_graph=True): the bucket all-reduces captured INSIDE the step's hipGraph (hooks live during
     the capture, side stream forked from the capturing stream), verified against eager gradients before use and abandoned

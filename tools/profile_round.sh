@@ -6,6 +6,8 @@
 #   <tag>_traffic_stress.json           S-stress rowgroup kernel: HBM bytes per launch from separate --pmc passes
 #   <tag>_traffic_fwd_fb15k237.json     headline graph's forward kernel (F = 2048): the same
 #   <tag>_stress_rowgroup_pmc.txt / <tag>_kbench_fwd_pmc.txt   the counter means those come from
+#   <tag>_train_{wn18rr,fb15k237}_kernel_stats.csv + _step.txt   fine-tuning steps (hipGraph replays): kernel summary, ms/step
+#   <tag>_step_trace_{fb15k237,codexs}.txt   one evaluation batch, kernel by kernel (rocprofv3 --kernel-trace)
 # usage (gpurun): bash tools/profile_round.sh r03
 tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -17,6 +19,20 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/bench" -o bench --
 grep "^{\"metric\"" "$out/bench_under_rocprof.log" | tail -1 > "$out/${tag}_bench_under_rocprof.json"
 find "$out/bench" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_bench_kernel_stats.csv" \;
 rm -rf "$out/bench"
+# fine-tuning steps (hipGraph replays) of the two fine-tuning shapes: per-kernel summary
+for wl in wn18rr fb15k237; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/train_$wl" -o train -- "$PY" tools/train_bench.py --workload S-$wl --graphed --steps 20 > "$out/train_$wl.log" 2>&1
+  find "$out/train_$wl" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_train_${wl}_kernel_stats.csv" \;
+  tail -1 "$out/train_$wl.log" > "$out/${tag}_train_${wl}_step.txt"
+  rm -rf "$out/train_$wl"
+done
+# one evaluation batch replayed as a hipGraph, kernel by kernel (headline graph and the small config-2 graph)
+for wl in fb15k237 codexs; do
+  WORKLOAD=S-$wl rocprofv3 --kernel-trace --output-format csv -d "$out/step_$wl" -o st -- "$PY" tools/debug/step_trace.py > "$out/step_$wl.log" 2>&1
+  d=$(dirname "$(find "$out/step_$wl" -name "*kernel_trace.csv" | tail -1)")
+  "$PY" tools/debug/step_trace_report.py "$d" > "$out/${tag}_step_trace_${wl}.txt" 2>&1
+  rm -rf "$out/step_$wl"
+done
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
   rocprofv3 --pmc $pass --output-format csv -d "$out/stress_$name" -- "$PY" tools/stress_bench.py --reps 2 --knob 0 > "$out/stress_$name.log" 2>&1

@@ -77,6 +77,7 @@ EXPORTS = (
     "ultra_relation_stack_inputs",
     "ultra_statistics_blocks",
     "ultra_statistics_f32",
+    "ultra_bce_adversarial_f32",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
     "ultra_relcsr_plan_temp_bytes",
@@ -154,6 +155,8 @@ def load():
     lib.ultra_statistics_blocks.argtypes = [i64]
     lib.ultra_statistics_f32.restype = i32
     lib.ultra_statistics_f32.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp]
+    lib.ultra_bce_adversarial_f32.restype = i32
+    lib.ultra_bce_adversarial_f32.argtypes = [vp, i64, i64, ctypes.c_float, vp, vp, vp]
     lib.ultra_relation_stack_inputs.restype = i32
     lib.ultra_relation_stack_inputs.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, vp, vp]
     lib.ultra_combine_backward_waves.restype = i32

@@ -21,7 +21,7 @@ import torch
 from . import _lib, _torch_ext
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -382,6 +382,36 @@ def statistics(values, repeated=None, repeat=0):
                                             b.numel() if b is not None else 0, int(repeat) if b is not None else 0,
                                             partials.data_ptr(), out.data_ptr(), _stream()))
     return out
+
+
+class _BCEAdversarial(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, temperature):
+        pred = pred.contiguous()
+        rows, cols = pred.shape
+        loss = torch.empty(rows, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        lib = _lib.load()
+        with torch.cuda.device(pred.device):
+            _lib.check(lib.ultra_bce_adversarial_f32(pred.data_ptr(), rows, cols, float(temperature), loss.data_ptr(),
+                                                     dpred.data_ptr(), _stream()))
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        (dpred,) = ctx.saved_tensors
+        return grad.unsqueeze(-1) * dpred, None
+
+
+def bce_adversarial_loss(pred, temperature):
+    """Per-row training loss of ``ultra/task.py:169-180`` for logits ``pred`` ``(B, 1 + K)`` (positive in column 0): binary
+    cross entropy with logits, negatives weighted by ``softmax(pred[:, 1:] / temperature)`` (no gradient through the
+    weights; ``temperature <= 0``: ``1 / K`` each), weighted mean per row -- forward and gradient in one launch
+    (``ultra_bce_adversarial_f32``).  Returns ``(B,)``."""
+    if pred.dim() != 2 or pred.dtype != torch.float32 or not pred.is_cuda:
+        raise RuntimeError("bce_adversarial_loss needs fp32 (B, 1 + K) logits on a HIP device (no CPU fallback)")
+    return _BCEAdversarial.apply(pred, float(temperature))
 
 
 def relation_stack_inputs(weights, h_index):

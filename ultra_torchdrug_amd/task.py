@@ -429,7 +429,9 @@ class KnowledgeGraphCompletion(nn.Module):
         pos_h_index, pos_t_index, pos_r_index = batch.t()
         names = {"bce": "binary cross entropy", "ce": "cross entropy", "ranking": "ranking loss"}
         for criterion, weight in self.criterion.items():
-            if criterion == "bce":                                                   # task.py:169-180
+            if criterion == "bce" and backend.get().accepts(pred) and pred.dtype == torch.float32 and pred.dim() == 2:
+                loss = backend.get().bce_adversarial_loss(pred, self.adversarial_temperature)     # task.py:169-180, one launch
+            elif criterion == "bce":                                                 # task.py:169-180
                 target = torch.zeros_like(pred)
                 target[:, 0] = 1
                 loss = F.binary_cross_entropy_with_logits(pred, target, reduction="none")
