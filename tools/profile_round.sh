@@ -23,7 +23,7 @@ rm -rf "$out/bench"
 for wl in wn18rr fb15k237; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/train_$wl" -o train -- "$PY" tools/train_bench.py --workload S-$wl --graphed --steps 20 > "$out/train_$wl.log" 2>&1
   find "$out/train_$wl" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_train_${wl}_kernel_stats.csv" \;
-  tail -1 "$out/train_$wl.log" > "$out/${tag}_train_${wl}_step.txt"
+  grep -h "ms/step" "$out/train_$wl.log" > "$out/${tag}_train_${wl}_step.txt"
   rm -rf "$out/train_$wl"
 done
 # one evaluation batch replayed as a hipGraph, kernel by kernel (headline graph and the small config-2 graph)
