@@ -217,7 +217,9 @@ int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd_host, const float 
  */
 int ultra_combine_forward_f32(const float *input, const float *update, const float *weight, const float *bias,
                               const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                              float *out, int64_t rows, int64_t dim, void *stream);
+                              float *out, float *z_out, int64_t rows, int64_t dim, void *stream);
+/* z_out (NULL in inference): [rows, 64], receives z = Linear(cat[input, update]) -- the LayerNorm's input -- for
+ * ultra_combine_backward_fused_f32, which then loads it instead of recomputing it (a third of its matrix work). */
 
 /* The same epilogue for the FIRST layer of a Bellman-Ford, whose `input` is the boundary itself (ultra/model.py:116-120):
  * row (v, q) of `input` -- rows = n_nodes * n_query, q fastest -- is boundary_value[q, :] where v == boundary_node[q] and
@@ -263,11 +265,12 @@ int ultra_combine_dxdu_f32(const float *d_z, const float *weight, const float *g
  * bits as ultra_combine_dxdu_f32, the parameter gradients come out finished (partials added in wave order).
  *   shortcut          : d_input += grad_out (the caller's `hidden + layer_input`, ultra/model.py:126-127)
  *   d_weight [64,128], d_bias [64] or NULL, d_ln_weight / d_ln_bias [64] (ignored without LayerNorm)
- *   partial_workspace : ultra_combine_backward_fused_waves() * (64 * 128 + 192) floats of scratch */
+ *   partial_workspace : ultra_combine_backward_fused_waves() * (64 * 128 + 192) floats of scratch
+ *   z                 : NULL, or the z_out of the layer's ultra_combine_forward_f32 (same bits as the recomputation) */
 int ultra_combine_backward_fused_waves(int device, int64_t rows, int *n_waves);
 int ultra_combine_backward_fused_f32(const float *input, const float *update, const float *weight, const float *bias,
                                      const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                                     const float *grad_out, float *d_input, float *d_update, float *d_weight,
+                                     const float *grad_out, const float *z, float *d_input, float *d_update, float *d_weight,
                                      float *d_bias, float *d_ln_weight, float *d_ln_bias, float *partial_workspace,
                                      size_t workspace_bytes, int64_t rows, int64_t dim, void *stream);
 

@@ -464,6 +464,40 @@ def test_training_metric_statistics_equal_the_reference_formulas():
         torch.testing.assert_close(metric_gpu[k].cpu().float(), metric_cpu[k].float(), rtol=2e-3, atol=1e-4), k
 
 
+def test_kept_pre_norm_output_gives_the_gradients_of_the_recomputation():
+    """Training forward with z_out (the Linear's output before LayerNorm kept for the backward) against the backward that
+    recomputes z: the same bits in every gradient (z is produced by the same fmaf chain), and z itself is the Linear's
+    output in the kernel's order."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(13)
+    for rows, queries, use_ln, shortcut in [(5, 3, True, True), (700, 16, True, True), (9000, 16, True, False), (1300, 8, False, True)]:
+        x = torch.randn(rows, queries, 64, generator=gen).to(dev)
+        u = torch.randn(rows, queries, 64, generator=gen).to(dev)
+        g = torch.randn(rows, queries, 64, generator=gen).to(dev)
+        lin = torch.nn.Linear(128, 64).to(dev)
+        norm = torch.nn.LayerNorm(64).to(dev) if use_ln else None
+        grads = {}
+        for keep in (True, False):
+            UF.KEEP_PRE_NORM = keep
+            try:
+                a, b = x.clone().requires_grad_(), u.clone().requires_grad_()
+                params = [lin.weight, lin.bias] + ([norm.weight, norm.bias] if use_ln else [])
+                out = UF.combine(a, b, lin.weight, lin.bias, norm.weight if use_ln else None, norm.bias if use_ln else None,
+                                 1e-5, True, shortcut)
+                grads[keep] = (out.detach(),) + torch.autograd.grad(out, [a, b] + params, grad_outputs=g)
+            finally:
+                UF.KEEP_PRE_NORM = False
+        for kept, recomputed in zip(grads[True], grads[False]):
+            assert torch.equal(kept, recomputed), (rows, queries, use_ln, shortcut)
+        z = torch.empty_like(x)
+        with torch.no_grad():
+            UF.combine_forward(x, u, lin.weight, lin.bias, norm.weight if use_ln else None, norm.bias if use_ln else None,
+                               1e-5, True, shortcut, z_out=z)
+            ref = lin(torch.cat([x, u], dim=-1))
+        torch.testing.assert_close(z, ref, rtol=2e-5, atol=2e-5)
+
+
 def test_fused_training_loss_equals_the_reference_chain():
     """ultra_bce_adversarial_f32 (loss rows + gradient in one launch) against the ATen chain of ultra/task.py:169-180 in
     fp64: binary_cross_entropy_with_logits, self-adversarial softmax weights without gradient, weighted mean per row."""

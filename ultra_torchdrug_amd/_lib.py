@@ -146,7 +146,7 @@ def load():
     lib.ultra_rspmm_backward_weight_f32.restype = i32
     lib.ultra_rspmm_backward_weight_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
     lib.ultra_combine_forward_f32.restype = i32
-    lib.ultra_combine_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, i64, vp]
+    lib.ultra_combine_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, i64, i64, vp]
     lib.ultra_combine_forward_boundary_f32.restype = i32
     lib.ultra_combine_forward_boundary_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, i64, vp]
     lib.ultra_prepare_queries.restype = i32
@@ -168,7 +168,7 @@ def load():
     lib.ultra_combine_backward_fused_waves.restype = i32
     lib.ultra_combine_backward_fused_waves.argtypes = [i32, i64, ctypes.POINTER(i32)]
     lib.ultra_combine_backward_fused_f32.restype = i32
-    lib.ultra_combine_backward_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp, vp, vp, vp,
+    lib.ultra_combine_backward_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp, vp, vp, vp, vp,
                                                      vp, vp, sz, i64, i64, vp]
     lib.ultra_linear_forward_f32.restype = i32
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]

@@ -680,6 +680,7 @@ struct CombineParams {
     int shortcut;
     // first layer of a Bellman-Ford (ultra_combine_forward_boundary_f32): `input` IS the boundary -- zero outside row
     // in_bnode[q] of query block q (ultra/model.py:106-107) -- and is synthesised instead of read; NULL otherwise
+    float *z_out;                // ZOUT (training): [rows, 64] the Linear's output before LayerNorm, kept for the backward
     const int32_t *in_bnode;     // [rpn]
     const float *in_bvec;        // [rpn, 64]
     int rpn;                     // rows per node = number of queries
@@ -693,7 +694,9 @@ struct CombineParams {
 // (up to kCbLdsQueries queries), 2 = read from memory (any number; the dependent loads make the prefetch synchronous).
 // Template parameters, not run-time branches in `fetch`: a branch that MAY load makes the compiler wait for every load
 // in flight at its join (vmcnt is in order) -- 129 vs 94 us -- and cost the common form registers (100 -> 145 us).
-template <bool PF, int BND = 0>
+// ZOUT: the training forward also writes z = Linear(cat[input, update]) (the LayerNorm's input) so that the fused backward
+// loads it instead of recomputing it -- a third of that kernel's matrix work.
+template <bool PF, int BND = 0, bool ZOUT = false>
 __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(const CombineParams p) {
     extern __shared__ __attribute__((aligned(16))) float cb_lds[];
     const int lane = threadIdx.x & 63;
@@ -816,6 +819,12 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
         for (int q = 0; q < 8; ++q) {
             const f32x4 d = *reinterpret_cast<const f32x4 *>(tile + ln_row * kCbStride + 64 + 32 * ln_half + 4 * q);
             v[4 * q + 0] = d.x; v[4 * q + 1] = d.y; v[4 * q + 2] = d.z; v[4 * q + 3] = d.w;
+            if constexpr (ZOUT) {       // this lane's half row of z (rows past the end: dropped by the descriptor's range)
+                const long long left_z = p.rows - row0;
+                const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(
+                    p.z_out + row0 * 64, 0, (int)(left_z < kCbRows ? left_z : kCbRows) * 256, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(qu4, d), rsrc_z, ln_row * 256 + ln_half * 128 + 16 * q, 0, 0);
+            }
         }
         if (p.gamma != nullptr) {
             float s = 0.0f;
@@ -1718,6 +1727,10 @@ static int combine_launch(const CombineParams &p, void *stream) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<true, 2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<false, 0, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(combine_kernel<true, 0, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_set[dev] = true;
     }
     const dim3 grid((unsigned)blocks), block(kCbWaves * 64);
@@ -1728,6 +1741,9 @@ static int combine_launch(const CombineParams &p, void *stream) {
     } else if (p.in_bnode != nullptr) {
         if (prefetch) hipLaunchKernelGGL((combine_kernel<true, 2>), grid, block, lds, st, p);
         else hipLaunchKernelGGL((combine_kernel<false, 2>), grid, block, lds, st, p);
+    } else if (p.z_out != nullptr) {
+        if (prefetch) hipLaunchKernelGGL((combine_kernel<true, 0, true>), grid, block, lds, st, p);
+        else hipLaunchKernelGGL((combine_kernel<false, 0, true>), grid, block, lds, st, p);
     } else {
         if (prefetch) hipLaunchKernelGGL((combine_kernel<true, 0>), grid, block, lds, st, p);
         else hipLaunchKernelGGL((combine_kernel<false, 0>), grid, block, lds, st, p);
@@ -1738,7 +1754,7 @@ static int combine_launch(const CombineParams &p, void *stream) {
 
 int ultra_combine_forward_f32(const float *input, const float *update, const float *weight, const float *bias,
                               const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                              float *out, int64_t rows, int64_t dim, void *stream) {
+                              float *out, float *z_out, int64_t rows, int64_t dim, void *stream) {
     if (dim != 64) return ULTRA_ERR_BAD_SHAPE;     // the shipped architecture: 64 -> 64 with a 128-wide concat
     if (rows < 0) return ULTRA_ERR_BAD_SHAPE;
     if (rows == 0) return ULTRA_OK;
@@ -1748,6 +1764,7 @@ int ultra_combine_forward_f32(const float *input, const float *update, const flo
     CombineParams p{};
     p.input = input; p.update = update; p.weight = weight; p.bias = bias; p.gamma = ln_weight; p.beta = ln_bias;
     p.out = out; p.rows = rows; p.eps = ln_eps; p.relu = relu; p.shortcut = shortcut;
+    p.z_out = z_out;
     return combine_launch(p, stream);
 }
 

@@ -264,12 +264,13 @@ def rspmm_backward_weight(csr, relation, input, output, output_grad, sum="add", 
 
 
 def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False,
-                    reuse_update=False, input_boundary=None):
+                    reuse_update=False, input_boundary=None, z_out=None):
     """Fused ``combine`` (+ shortcut) of one layer, forward only: ``[input +] relu(LN(Linear(cat[input, update])))``
     (``ultra/layer.py:386-392``, ``ultra/model.py:126-127``).  ``input`` / ``update``: ``(..., 64)`` fp32 on the GPU.
     ``reuse_update``: the caller owns ``update`` and does not need it afterwards -- the result is written over it
     (every 32-row tile is read completely before it is written), which keeps a layer's working set at two
-    ``(N, B, 64)`` tensors instead of three."""
+    ``(N, B, 64)`` tensors instead of three.  ``z_out`` (training): an ``input``-shaped fp32 tensor that receives the Linear's
+    output before LayerNorm, for the fused backward (``ultra_combine_backward_fused_f32``) to load instead of recompute."""
     if input_boundary is not None:
         # first layer: `input` is the boundary (model.py:116-120), given as (node int32 (B,), value fp32 (B, 64)); the kernel
         # synthesises its rows -- row (v, q) = value[q] where v == node[q], +0 elsewhere -- instead of reading (N, B, 64) zeros
@@ -303,13 +304,17 @@ def combine_forward(input, update, weight, bias, ln_weight=None, ln_bias=None, l
     input, update = input.contiguous(), update.contiguous()
     out = update if reuse_update else torch.empty_like(input)
     rows = input.numel() // 64
+    if z_out is not None and (z_out.shape != input.shape or z_out.dtype != torch.float32 or not z_out.is_contiguous()
+                              or z_out.device != input.device):
+        raise RuntimeError("combine_forward: z_out must be a contiguous fp32 tensor of the input's shape on its device")
     lib = _lib.load()
     with torch.cuda.device(input.device):
         _lib.check(lib.ultra_combine_forward_f32(
             input.data_ptr(), update.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
             ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
             ln_bias.contiguous().data_ptr() if ln_weight is not None else None,
-            float(ln_eps), int(bool(relu)), int(bool(shortcut)), out.data_ptr(), rows, 64, _stream()))
+            float(ln_eps), int(bool(relu)), int(bool(shortcut)), out.data_ptr(),
+            z_out.data_ptr() if z_out is not None else None, rows, 64, _stream()))
     return out
 
 
@@ -648,6 +653,14 @@ def strict_negatives(keys, anchor, rel, n_rel, n_node, rand):
     return out
 
 
+# Training, opt-in (ULTRA_KEEP_PRE_NORM=1): the fused epilogue's forward keeps z = Linear(cat[input, update]) (one more
+# (N, B, 64) tensor per layer) and the fused backward loads it instead of recomputing it -- a third of that kernel's matrix
+# work, identical gradients.  Measured on an MI355X it only moves the backward kernel 380 -> 365 us at 655 k rows (the kernel
+# waits on memory 38 % of its cycles, PMC; its matrix cores are busy 44 %) and the forward pays 12 us for writing z: no gain
+# per step, hence off by default.
+KEEP_PRE_NORM = __import__("os").environ.get("ULTRA_KEEP_PRE_NORM", "0") == "1"
+
+
 class _CombineFunction(torch.autograd.Function):
     """Fused epilogue with a fused backward (training).  Forward = ``combine_forward``; only the layer's inputs are
     saved.  Backward: ``libultra_rspmm`` recomputes z, applies the ReLU mask and LayerNorm-backward and reduces
@@ -655,14 +668,15 @@ class _CombineFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut):
-        out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
-        ctx.save_for_backward(input, update, weight, bias, ln_weight, ln_bias)
+        z = torch.empty_like(input, memory_format=torch.contiguous_format) if KEEP_PRE_NORM else None
+        out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut, z_out=z)
+        ctx.save_for_backward(input, update, weight, bias, ln_weight, ln_bias, z)
         ctx.flags = (float(ln_eps), bool(relu), bool(shortcut))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        input, update, weight, bias, ln_weight, ln_bias = ctx.saved_tensors
+        input, update, weight, bias, ln_weight, ln_bias, z = ctx.saved_tensors
         ln_eps, relu, shortcut = ctx.flags
         grad_out = grad_out.contiguous()
         input_c, update_c = input.contiguous(), update.contiguous()
@@ -687,7 +701,8 @@ class _CombineFunction(torch.autograd.Function):
                 _lib.check(lib.ultra_combine_backward_fused_f32(
                     input_c.data_ptr(), update_c.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
                     ln_weight.contiguous().data_ptr() if has_ln else None, ln_bias.contiguous().data_ptr() if has_ln else None,
-                    ln_eps, int(relu), int(shortcut), grad_out.data_ptr(), d_input.data_ptr(), d_update.data_ptr(),
+                    ln_eps, int(relu), int(shortcut), grad_out.data_ptr(), z.data_ptr() if z is not None else None,
+                    d_input.data_ptr(), d_update.data_ptr(),
                     d_weight.data_ptr(), d_bias.data_ptr(), d_g.data_ptr() if has_ln else None,
                     d_b.data_ptr() if has_ln else None, ws.data_ptr(), ws.numel() * 4, rows, 64, _stream()))
             needs = ctx.needs_input_grad
@@ -811,16 +826,17 @@ class _SumLayerFunction(torch.autograd.Function):
         update = rspmm_forward(csr, relation, flat, "add", mul, add_rows=None if add_rows is None else add_rows.flatten(1),
                                boundary=boundary)
         update = update.view(shape)
-        out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut)
+        z = torch.empty_like(update) if KEEP_PRE_NORM else None
+        out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut, z_out=z)
         ctx.csr, ctx.mul, ctx.b_node, ctx.has_add = csr, mul, b_node, add_rows is not None
         ctx.flags = (float(ln_eps), bool(relu), bool(shortcut))
-        ctx.save_for_backward(relation, input, update, weight, bias, ln_weight, ln_bias)
+        ctx.save_for_backward(relation, input, update, weight, bias, ln_weight, ln_bias, z)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         import ctypes
-        relation, input, update, weight, bias, ln_weight, ln_bias = ctx.saved_tensors
+        relation, input, update, weight, bias, ln_weight, ln_bias, z = ctx.saved_tensors
         ln_eps, relu, shortcut = ctx.flags
         needs = ctx.needs_input_grad
         shape = input.shape
@@ -842,7 +858,8 @@ class _SumLayerFunction(torch.autograd.Function):
             _lib.check(lib.ultra_combine_backward_fused_f32(
                 input_c.data_ptr(), update_c.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
                 ln_weight.contiguous().data_ptr() if has_ln else None, ln_bias.contiguous().data_ptr() if has_ln else None,
-                ln_eps, int(relu), int(shortcut), grad_out.data_ptr(), d_input.data_ptr(), d_update.data_ptr(),
+                ln_eps, int(relu), int(shortcut), grad_out.data_ptr(), z.data_ptr() if z is not None else None,
+                d_input.data_ptr(), d_update.data_ptr(),
                 d_weight.data_ptr(), d_bias.data_ptr(), d_g.data_ptr() if has_ln else None,
                 d_b.data_ptr() if has_ln else None, ws.data_ptr(), ws.numel() * 4, rows, 64, _stream()))
         # the edge gradient accumulates into the epilogue's d_input (same buffer) inside the rspmm backward
