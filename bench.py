@@ -793,7 +793,7 @@ def main():
                             "edges_per_s": roofline["edges_per_s"], "frac_of_hbm_peak": roofline["frac"],
                             "plan_build_s": roofline["plan_build_s"]})
         result = {
-            "metric": "edges aggregated/sec, FB15k237-shaped 6L x 64d rspmm Bellman-Ford (predict: 18 rspmm/batch)",
+            "metric": "edges aggregated/sec, FB15k237-shaped 6L x 64d rspmm Bellman-Ford (predict: the reference's 18 rspmm layers per batch as 6 relation-graph + 6 entity-graph launches, tails and heads in one pass)",
             "value": visited / elapsed,
             "unit": "edges aggregated/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
