@@ -1166,6 +1166,8 @@ int launch_rowgroup(RowGroupParams &q, bool backward, int sum_op, int mul_op, bo
     const int width = 4 * group;
     q.n_tiles = (int)((F + width - 1) / width);
     q.split = kXcd / gcd_int(q.n_tiles, kXcd);
+    // a part's rows are stored through one buffer descriptor with 32-bit offsets: keep rows_per_part * row bytes < 4 GiB
+    while (((long long)q.n_rows + q.split - 1) / q.split * F * 4 >= (1LL << 32) - 65536 && q.split < (1 << 20)) q.split *= 2;
     q.n_slots = q.n_tiles * q.split;
     q.blocks_per_label = (n_cu + kXcd - 1) / kXcd;
     const size_t lds_need = (size_t)q.n_rel * width * sizeof(float);
