@@ -171,6 +171,20 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
                              const float *relation, const int32_t *boundary_node, const float *boundary_value,
                              int64_t block, float *out, int64_t n_dst, int64_t n_rel, int64_t F, void *stream);
 
+/* d_input of the FIRST layer's rspmm in training, at the rows that are used: that layer's input is the boundary
+ * (/root/reference/ultra/model.py:106-107,116-120), whose gradient autograd consumes at row (boundary_node[q], query block q)
+ * only.  For every query q:
+ *     d_input[boundary_node[q], q*64 .. q*64+63] += sum over out-edges (u -> v, r) of u = boundary_node[q]:
+ *                                                   (output_grad[v, same columns] * w) [* relation[r, same columns]]
+ * -- the out-edges of one node per query instead of the d_input pass over all E edges for all queries.  by_src / src_ptr:
+ * as for ultra_rspmm_frontier_f32; F = n_query * 64; mul_op = add has no relation factor.  Added IN PLACE (d_input holds the
+ * epilogue's share already); the other rows of d_input do not receive their edge gradient. */
+size_t ultra_rspmm_backward_boundary_rows_workspace(int64_t n_query);      /* bytes of scratch for the call below */
+int ultra_rspmm_backward_boundary_rows_f32(const ultra_segments *by_src, const int32_t *src_ptr, const float *relation,
+                                           const float *output_grad, const int32_t *boundary_node, float *d_input,
+                                           float *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_query, int64_t F,
+                                           int mul_op, void *stream);
+
 /*
  * Gradients of the call above w.r.t. input and relation
  * replaces rspmm_{sum}_{mul}_backward_cuda(sparse, relation, input, output, output_grad).

@@ -132,7 +132,7 @@ class OracleFunctional:
         return out + (add_rows if boundary is None else self._dense_boundary(boundary, out.shape[0]))
 
     def sum_layer(self, csr, relation, input, boundary_dense, boundary_sparse, mul, weight, bias, ln_weight=None,
-                  ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False):
+                  ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False, input_is_boundary=False):
         """The layer the reference's way, op by op (layer.py:298-392, model.py:126-127)."""
         shape = input.shape
         if boundary_sparse is not None:

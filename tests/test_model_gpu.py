@@ -464,6 +464,52 @@ def test_training_metric_statistics_equal_the_reference_formulas():
         torch.testing.assert_close(metric_gpu[k].cpu().float(), metric_cpu[k].float(), rtol=2e-3, atol=1e-4), k
 
 
+def test_first_layer_backward_at_the_boundary_rows_gives_the_query_gradients_of_the_full_pass():
+    """Training: the first layer's input is the boundary, whose gradient is consumed at row (anchor_q, q) only
+    (scatter_add_'s backward, model.py:106-107) -- ultra_rspmm_backward_boundary_rows_f32 computes the rspmm's edge gradient
+    at those rows alone.  Every parameter gradient of a whole training step must agree with the step that runs the full
+    d_input pass (the two sum a hub's out-edges in different orders: fp32 tolerance), and the kernel's rows with the rows
+    of the full pass."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    task, triples = _build((1200, 9000, 12))
+    task.num_negative = 32
+    task.to(dev).train()
+    batch = torch.from_numpy(triples[:16]).to(dev)
+    grads = {}
+    for rows_only in (True, False):
+        UF.BOUNDARY_ROWS_BACKWARD = rows_only
+        try:
+            task.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            loss, _ = task(batch)
+            loss.backward()
+            grads[rows_only] = {k: p.grad.detach().clone() for k, p in task.named_parameters() if p.grad is not None}
+        finally:
+            UF.BOUNDARY_ROWS_BACKWARD = True
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 20
+    for k in grads[True]:
+        scale = grads[False][k].abs().max().item()
+        assert (grads[True][k] - grads[False][k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
+    # the kernel alone: rows (node_q, q) of the full d_input
+    csr = task.model._undirected(task.fact_graph).relcsr
+    n, Q = csr.shape[1], 8
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    relation = torch.randn(csr.shape[2], Q * 64, generator=gen).to(dev)
+    grad = torch.randn(n, Q * 64, generator=gen).to(dev)
+    x = torch.randn(n, Q * 64, generator=gen).to(dev)
+    node = torch.randint(0, n, (Q,), generator=gen).to(torch.int32).to(dev)
+    for mul in ("mul", "add"):
+        full, _ = UF.rspmm_backward(csr, relation, x, None, grad, "add", mul, need_relation=False)
+        rows = UF.rspmm_backward_boundary_rows(csr, relation, grad, node, torch.zeros(n, Q * 64, device=dev), mul)
+        picked = rows.view(n, Q, 64)[node.long(), torch.arange(Q, device=dev)]
+        want = full.view(n, Q, 64)[node.long(), torch.arange(Q, device=dev)]
+        torch.testing.assert_close(picked, want, rtol=2e-5, atol=2e-5)
+        others = rows.view(n, Q, 64).clone()
+        others[node.long(), torch.arange(Q, device=dev)] = 0
+        assert not others.any()
+
+
 def test_kept_pre_norm_output_gives_the_gradients_of_the_recomputation():
     """Training forward with z_out (the Linear's output before LayerNorm kept for the backward) against the backward that
     recomputes z: the same bits in every gradient (z is produced by the same fmaf chain), and z itself is the Linear's

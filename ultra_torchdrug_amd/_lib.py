@@ -54,6 +54,8 @@ EXPORTS = (
     "ultra_rspmm_fwd_f32",
     "ultra_rspmm_forward_boundary_f32",
     "ultra_rspmm_frontier_f32",
+    "ultra_rspmm_backward_boundary_rows_f32",
+    "ultra_rspmm_backward_boundary_rows_workspace",
     "ultra_rspmm_backward_f32",
     "ultra_rspmm_backward_accumulate_f32",
     "ultra_rspmm_backward_weight_f32",
@@ -136,6 +138,10 @@ def load():
     lib.ultra_rspmm_fwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_forward_boundary_f32.restype = i32
     lib.ultra_rspmm_forward_boundary_f32.argtypes = [seg, vp, vp, vp, vp, i64, vp, vp, sz, i64, i64, i64, i32, i32, vp]
+    lib.ultra_rspmm_backward_boundary_rows_f32.restype = i32
+    lib.ultra_rspmm_backward_boundary_rows_f32.argtypes = [seg, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i32, vp]
+    lib.ultra_rspmm_backward_boundary_rows_workspace.restype = sz
+    lib.ultra_rspmm_backward_boundary_rows_workspace.argtypes = [i64]
     lib.ultra_rspmm_frontier_f32.restype = i32
     lib.ultra_rspmm_frontier_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp]
     lib.ultra_rspmm_backward_f32.restype = i32

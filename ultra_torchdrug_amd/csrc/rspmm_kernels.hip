@@ -1616,6 +1616,39 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
     return ULTRA_OK;
 }
 
+size_t ultra_rspmm_backward_boundary_rows_workspace(int64_t n_query) {
+    return n_query <= 0 ? 0 : (size_t)n_query * kBRowsWaves * 64 * sizeof(float);
+}
+
+int ultra_rspmm_backward_boundary_rows_f32(const ultra_segments *by_src, const int32_t *src_ptr, const float *relation,
+                                           const float *output_grad, const int32_t *boundary_node, float *d_input,
+                                           float *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_query, int64_t F,
+                                           int mul_op, void *stream) {
+    int rc = check_segments(by_src);
+    if (rc) return rc;
+    if (n_src < 0 || n_query < 0 || n_query > 65535 || F != n_query * 64 || (mul_op != ULTRA_MUL_MUL && mul_op != ULTRA_MUL_ADD))
+        return ULTRA_ERR_BAD_SHAPE;
+    if (n_query == 0 || n_src == 0) return ULTRA_OK;
+    if (src_ptr == nullptr || boundary_node == nullptr || d_input == nullptr || workspace == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (by_src->n_edges > 0 && (output_grad == nullptr || (mul_op == ULTRA_MUL_MUL && relation == nullptr))) return ULTRA_ERR_NULL_POINTER;
+    if (workspace_bytes < ultra_rspmm_backward_boundary_rows_workspace(n_query)) return ULTRA_ERR_WORKSPACE;
+    BoundaryRowsParams p;
+    p.src_ptr = src_ptr; p.dst = by_src->node_a; p.rel = by_src->rel; p.weight = by_src->weight;
+    p.relation = mul_op == ULTRA_MUL_MUL ? relation : nullptr; p.grad = output_grad; p.bnode = boundary_node;
+    p.partial = workspace; p.d_input = d_input; p.F = F;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(kBRowsSlices, (unsigned)n_query), block(256);
+    const bool unit_w = by_src->weight == nullptr, has_rel = mul_op == ULTRA_MUL_MUL;
+    if (unit_w && has_rel) hipLaunchKernelGGL((boundary_rows_partial_kernel<true, true>), grid, block, 0, s, p);
+    else if (unit_w) hipLaunchKernelGGL((boundary_rows_partial_kernel<true, false>), grid, block, 0, s, p);
+    else if (has_rel) hipLaunchKernelGGL((boundary_rows_partial_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((boundary_rows_partial_kernel<false, false>), grid, block, 0, s, p);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(boundary_rows_reduce_kernel, dim3((unsigned)n_query), dim3(64), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
 int ultra_rspmm_backward_f32(const ultra_segments *by_src, const ultra_segments *by_rel, const float *relation,
                              const float *input, const float *output, const float *output_grad, float *d_input,
                              float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_dst,

@@ -248,6 +248,30 @@ def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mu
     return d_input, d_relation
 
 
+def rspmm_backward_boundary_rows(csr, relation, output_grad, boundary_node, d_input, mul="mul"):
+    """First layer of a Bellman-Ford in training: the rspmm's edge gradient of ``input`` at the rows autograd consumes -- row
+    ``boundary_node[q]`` of query block ``q`` (the layer's input is the boundary, ``ultra/model.py:106-107,116-120``) -- added
+    IN PLACE into ``d_input`` ``(N_src, Q * 64)`` (``ultra_rspmm_backward_boundary_rows_f32``: the out-edges of one node per
+    query instead of the ``d_input`` pass over every edge).  Sum aggregation only."""
+    _, mul_op = _ops("add", mul)
+    n_query = boundary_node.shape[0]
+    F = n_query * 64
+    if (boundary_node.dtype != torch.int32 or not boundary_node.is_contiguous() or d_input.dtype != torch.float32
+            or not d_input.is_contiguous() or tuple(d_input.shape) != (csr.shape[1], F) or not output_grad.is_contiguous()
+            or tuple(output_grad.shape) != (csr.shape[0], F) or output_grad.dtype != torch.float32
+            or tuple(relation.shape) != (csr.shape[2], F) or not relation.is_contiguous() or csr.shape[0] != csr.shape[1]):
+        raise RuntimeError("rspmm_backward_boundary_rows: contiguous fp32 (N, Q * 64) gradients, int32 (Q,) nodes, a square adjacency")
+    src_ptr, _ = csr.frontier_index
+    lib = _lib.load()
+    ws = torch.empty(max(int(lib.ultra_rspmm_backward_boundary_rows_workspace(n_query)) // 4, 1), dtype=torch.float32,
+                     device=d_input.device)
+    with torch.cuda.device(d_input.device):
+        _lib.check(lib.ultra_rspmm_backward_boundary_rows_f32(
+            csr.by_src.pointer, src_ptr.data_ptr(), relation.data_ptr(), output_grad.data_ptr(), boundary_node.data_ptr(),
+            d_input.data_ptr(), ws.data_ptr(), ws.numel() * 4, csr.shape[1], n_query, F, mul_op, _stream()))
+    return d_input
+
+
 def rspmm_backward_weight(csr, relation, input, output, output_grad, sum="add", mul="mul"):
     """d(values) of the coalesced edges (forward-plan order)."""
     sum_op, mul_op = _ops(sum, mul)
@@ -809,6 +833,11 @@ class _RSPMMFunction(torch.autograd.Function):
         return d_sparse, d_relation, d_input, None, None, None, d_add, None, d_value
 
 
+# Training, first layer (the caller's `input_is_boundary` promise): the edge gradient of `input` only at the boundary rows
+# (see rspmm_backward_boundary_rows).  ULTRA_BOUNDARY_ROWS_BACKWARD=0: the full d_input pass.
+BOUNDARY_ROWS_BACKWARD = __import__("os").environ.get("ULTRA_BOUNDARY_ROWS_BACKWARD", "1") != "0"
+
+
 class _SumLayerFunction(torch.autograd.Function):
     """One Bellman-Ford layer with summed messages as ONE autograd node:
     ``out = combine(input, rspmm(adjacency, relation, input, sum="add") + boundary)``
@@ -819,7 +848,7 @@ class _SumLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, csr, relation, input, add_rows, b_node, b_value, mul, weight, bias, ln_weight, ln_bias, ln_eps,
-                relu, shortcut):
+                relu, shortcut, input_is_boundary=False):
         shape = input.shape                                      # (N, B, 64)
         flat = input.flatten(1)
         boundary = None if b_node is None else (b_node, b_value.detach())
@@ -829,6 +858,8 @@ class _SumLayerFunction(torch.autograd.Function):
         z = torch.empty_like(update) if KEEP_PRE_NORM else None
         out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut, z_out=z)
         ctx.csr, ctx.mul, ctx.b_node, ctx.has_add = csr, mul, b_node, add_rows is not None
+        # first layer: `input` is the boundary, whose gradient is consumed at row (b_node[q], q) only
+        ctx.boundary_rows_only = bool(input_is_boundary) and b_node is not None and BOUNDARY_ROWS_BACKWARD
         ctx.flags = (float(ln_eps), bool(relu), bool(shortcut))
         ctx.save_for_backward(relation, input, update, weight, bias, ln_weight, ln_bias, z)
         return out
@@ -864,9 +895,14 @@ class _SumLayerFunction(torch.autograd.Function):
                 d_b.data_ptr() if has_ln else None, ws.data_ptr(), ws.numel() * 4, rows, 64, _stream()))
         # the edge gradient accumulates into the epilogue's d_input (same buffer) inside the rspmm backward
         flat_du = d_update.flatten(1)
-        d_in, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,
-                                          need_input=needs[2], need_relation=needs[1],
-                                          d_input_add=d_input.flatten(1) if needs[2] else None)
+        if ctx.boundary_rows_only and needs[2]:
+            _, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,
+                                           need_input=False, need_relation=needs[1])
+            d_in = rspmm_backward_boundary_rows(ctx.csr, relation.contiguous(), flat_du, ctx.b_node, d_input.flatten(1), ctx.mul)
+        else:
+            d_in, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,
+                                              need_input=needs[2], need_relation=needs[1],
+                                              d_input_add=d_input.flatten(1) if needs[2] else None)
         d_add = d_update if (ctx.has_add and needs[3]) else None
         d_value = None
         if ctx.b_node is not None and needs[5]:
@@ -874,11 +910,11 @@ class _SumLayerFunction(torch.autograd.Function):
             d_value = d_update.view(shape[0], n_query, -1)[ctx.b_node.long(), torch.arange(n_query, device=dev)]
         return (None, d_relation, d_in.view(shape) if d_in is not None else None, d_add, None, d_value, None,
                 d_weight if needs[7] else None, d_bias if needs[8] else None, d_g if (has_ln and needs[9]) else None,
-                d_b if (has_ln and needs[10]) else None, None, None, None)
+                d_b if (has_ln and needs[10]) else None, None, None, None, None)
 
 
 def sum_layer(csr, relation, input, boundary_dense, boundary_sparse, mul, weight, bias, ln_weight=None, ln_bias=None,
-              ln_eps=1e-5, relu=True, shortcut=False):
+              ln_eps=1e-5, relu=True, shortcut=False, input_is_boundary=False):
     """A whole sum-aggregation layer for TRAINING as one autograd node (see :class:`_SumLayerFunction`):
     ``[input +] relu(LN(Linear(cat[input, rspmm(csr, relation, input) + boundary])))``.  ``input``: ``(N, B, 64)``;
     ``relation``: ``(R, B * 64)``; the boundary either dense ``(N, B, 64)`` or sparse ``(node int32 (B,), value (B, 64))``."""
@@ -886,7 +922,7 @@ def sum_layer(csr, relation, input, boundary_dense, boundary_sparse, mul, weight
     b_node, b_value = (None, None) if boundary_sparse is None else boundary_sparse
     add_rows = boundary_dense if boundary_sparse is None else None
     return _SumLayerFunction.apply(csr, relation, input, add_rows, b_node, b_value, mul, weight, bias, ln_weight, ln_bias,
-                                   ln_eps, relu, shortcut)
+                                   ln_eps, relu, shortcut, input_is_boundary)
 
 
 def rspmm_sum_plus(sparse, relation, input, add_rows, mul="mul", boundary=None):
