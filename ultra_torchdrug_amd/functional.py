@@ -852,8 +852,15 @@ class _SumLayerFunction(torch.autograd.Function):
         shape = input.shape                                      # (N, B, 64)
         flat = input.flatten(1)
         boundary = None if b_node is None else (b_node, b_value.detach())
-        update = rspmm_forward(csr, relation, flat, "add", mul, add_rows=None if add_rows is None else add_rows.flatten(1),
-                               boundary=boundary)
+        if (input_is_boundary and boundary is not None and BOUNDARY_ROWS_BACKWARD and frontier_supported("add", mul, flat.shape[1])
+                and csr.shape[0] == csr.shape[1]
+                and (torch.cuda.is_current_stream_capturing() or bool(torch.isfinite(relation).all()))):
+            # first layer: only the boundary nodes' out-edges carry a message (same bits as the full kernel, finite tables:
+            # see rspmm_frontier) -- as in inference
+            update = rspmm_frontier(csr, relation.detach(), boundary)
+        else:
+            update = rspmm_forward(csr, relation, flat, "add", mul, add_rows=None if add_rows is None else add_rows.flatten(1),
+                                   boundary=boundary)
         update = update.view(shape)
         z = torch.empty_like(update) if KEEP_PRE_NORM else None
         out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut, z_out=z)
