@@ -577,7 +577,9 @@ __global__ __launch_bounds__(kBlock) void packed_kernel(const PParams p) {
 }
 
 // out[row] = epilogue( partial[first] (+) partial[first+1] (+) ... ) in piece order.
-template <int RED>
+// UN: piece sums in flight per wave.  16 for graphs whose split rows have a few dozen pieces; 64 where they have hundreds
+// (d_relation of a relation graph: 4 rows of ~900 pieces each -- 64 waves in all -- 41 -> 15 us); same order of additions.
+template <int RED, int UN = kFixUnroll>
 __global__ __launch_bounds__(256) void fixup_kernel(const FixParams p) {
     const int lane = threadIdx.x & 63;
     const int wave_global = uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -591,15 +593,15 @@ __global__ __launch_bounds__(256) void fixup_kernel(const FixParams p) {
     const int first = p.long_rows[lr * 3 + 1];
     const int n = p.long_rows[lr * 3 + 2];
     float acc = identity<RED>();
-    for (int k0 = 0; k0 < n; k0 += kFixUnroll) {
-        float v[kFixUnroll];
+    for (int k0 = 0; k0 < n; k0 += UN) {
+        float v[UN];
 #pragma unroll
-        for (int u = 0; u < kFixUnroll; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const int k = min(k0 + u, n - 1);
             v[u] = p.partial[(long long)(first + k) * p.F + col];
         }
 #pragma unroll
-        for (int u = 0; u < kFixUnroll; ++u)
+        for (int u = 0; u < UN; ++u)
             if (k0 + u < n) acc = reduce<RED>(acc, v[u]);
     }
     if (p.add_rows != nullptr) acc = reduce<RED>(acc, p.add_rows[(long long)row * p.F + col]);
@@ -1397,7 +1399,10 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
         const long long waves = (long long)fp.n_long * n_tiles;
         const int fgrid = (int)((waves + 3) / 4);
         const int red = (KIND == KIND_FWD) ? sum_op : ULTRA_SUM_ADD;
-        if (red == ULTRA_SUM_ADD) hipLaunchKernelGGL(fixup_kernel<ULTRA_SUM_ADD>, dim3(fgrid), dim3(256), 0, stream, fp);
+        const bool many_pieces = seg->n_pieces >= 128 * seg->n_long_rows;       // on average >= 128 pieces per split row
+        if (red == ULTRA_SUM_ADD && many_pieces)
+            hipLaunchKernelGGL((fixup_kernel<ULTRA_SUM_ADD, 64>), dim3(fgrid), dim3(256), 0, stream, fp);
+        else if (red == ULTRA_SUM_ADD) hipLaunchKernelGGL(fixup_kernel<ULTRA_SUM_ADD>, dim3(fgrid), dim3(256), 0, stream, fp);
         else if (red == ULTRA_SUM_MIN) hipLaunchKernelGGL(fixup_kernel<ULTRA_SUM_MIN>, dim3(fgrid), dim3(256), 0, stream, fp);
         else hipLaunchKernelGGL(fixup_kernel<ULTRA_SUM_MAX>, dim3(fgrid), dim3(256), 0, stream, fp);
         HIP_TRY(hipGetLastError());
