@@ -1,0 +1,34 @@
+"""profiles/<tag>_configs.md from bench.py's JSON line (<tag>_bench_under_rocprof.json): one row per BASELINE config."""
+import json
+import sys
+
+
+def main(path, out):
+    j = json.load(open(path))
+    rows = ["| config | what | shape | this run |", "|---|---|---|---|"]
+    for c in j["config"]["configs"]:
+        k = c["config"]
+        if k == 1:
+            got = "predict + filtered rank %.0f ms per batch on the CPU kernels" % c["predict_plus_rank_ms_per_batch"]
+        elif k == 2:
+            got = ("predict %.3f ms per batch; entity forward kernel %.1f us = %.1f TB/s algorithmic (%.2f of the XCD-L2 peak)"
+                   % (c["predict_ms_per_batch"], c["entity_fwd_kernel_us"], c["entity_fwd_kernel_algorithmic_GBps"] / 1e3,
+                      c["entity_fwd_kernel_frac_of_l2_peak"]))
+        elif k == 3:
+            s = c["finetune_step"]
+            got = ("operator fwd %.1f us, bwd %.1f us; fine-tune step median %.2f ms (p10 %.2f, p90 %.2f, max %.2f; n = %d)"
+                   % (c["operator_fwd_us"], c["operator_bwd_us"], s["median_ms"], s["p10_ms"], s["p90_ms"], s["max_ms"], s["n"]))
+        elif k == 4:
+            s = c["step"]
+            got = ("captured step median %.1f ms (min %.1f, max %.1f; graphs drawn %s); eager step %.1f ms"
+                   % (s["median_ms"], s["min_ms"], s["max_ms"], c["graphs_drawn"], c["eager_step_ms"]))
+        else:
+            got = "operator fwd %.2f ms = %.2e edges/s = %.3f of the 8 TB/s HBM peak" % (c["operator_fwd_ms"], c["edges_per_s"], c["frac_of_hbm_peak"])
+        rows.append("| %d | %s | %s | %s |" % (k, c["name"], c["shape"], got))
+    head = ("Per-config timings of `%s` (one `bench.py` run under rocprofv3; headline: %.3f ms per evaluation batch, "
+            "%.3e entity-graph edge messages/s).\n\n" % (path.split("/")[-1], j["ms_per_step"], j["value"]))
+    open(out, "w").write(head + "\n".join(rows) + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -77,3 +77,4 @@ for prefix, pattern, name, algo, cmd, txt in (
 PY
 rm -rf "$out"/stress_* "$out"/fwd_*
 ls -la "$out"
+"$PY" tools/configs_table.py "$out/${tag}_bench_under_rocprof.json" "$out/${tag}_configs.md"
