@@ -280,13 +280,17 @@ int ultra_combine_dxdu_f32(const float *d_z, const float *weight, const float *g
  *   shortcut          : d_input += grad_out (the caller's `hidden + layer_input`, ultra/model.py:126-127)
  *   d_weight [64,128], d_bias [64] or NULL, d_ln_weight / d_ln_bias [64] (ignored without LayerNorm)
  *   partial_workspace : ultra_combine_backward_fused_waves() * (64 * 128 + 192) floats of scratch
- *   z                 : NULL, or the z_out of the layer's ultra_combine_forward_f32 (same bits as the recomputation) */
+ *   z                 : NULL, or the z_out of the layer's ultra_combine_forward_f32 (same bits as the recomputation)
+ *   tile_list, n_list : NULL / 0, or the 32-row tiles (row / 32, ascending, < 0 = padding) outside which grad_out is zero by
+ *                       the caller's word -- the LAST layer of a Bellman-Ford in training, whose output is read at the candidate
+ *                       entities' rows only (/root/reference/ultra/model.py:177-183): d_input / d_update are zero-filled and
+ *                       only the listed tiles are computed (z is ignored in this form) */
 int ultra_combine_backward_fused_waves(int device, int64_t rows, int *n_waves);
 int ultra_combine_backward_fused_f32(const float *input, const float *update, const float *weight, const float *bias,
                                      const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
                                      const float *grad_out, const float *z, float *d_input, float *d_update, float *d_weight,
                                      float *d_bias, float *d_ln_weight, float *d_ln_bias, float *partial_workspace,
-                                     size_t workspace_bytes, int64_t rows, int64_t dim, void *stream);
+                                     size_t workspace_bytes, const int32_t *tile_list, int64_t n_list, int64_t rows, int64_t dim, void *stream);
 
 
 /*
@@ -353,6 +357,13 @@ int ultra_prepare_queries(const int64_t *batch, const float *rel_rep, int64_t st
 int ultra_relation_stack_inputs(const float *const *weights, int64_t n_layers, int64_t n_rel, int64_t n_query,
                                 const int64_t *h_index, int64_t h_stride, float *tables, float *ones, int32_t *node32,
                                 void *stream);
+
+/* Training, last layer: the distinct 32-row tiles (row / 32) of an [n_rows = N * n_query, 64] activation that hold the rows
+ * (t_index[b, j] * n_query + b) -- where the gradient of hidden[t_index, arange(B)] (/root/reference/ultra/model.py:177-183) is
+ * non-zero -- ascending, -1 padded to n_batch * per_row entries, in one launch: the tile_list of
+ * ultra_combine_backward_fused_f32.  n_rows <= 32 Mi (ULTRA_ERR_BAD_SHAPE above: the caller builds the list itself). */
+int ultra_candidate_tiles(const int64_t *t_index, int64_t n_batch, int64_t per_row, int64_t n_query, int64_t n_rows, int32_t *out,
+                          void *stream);
 
 /* Training metrics: norm, mean and unbiased standard deviation of the values { a[0 .. n_a) } together with every b[0 .. n_b)
  * taken b_repeat times, in two launches with double-precision accumulation:  out[0..2] = (norm, mean, std).

@@ -510,6 +510,47 @@ def test_first_layer_backward_at_the_boundary_rows_gives_the_query_gradients_of_
         assert not others.any()
 
 
+def test_last_layer_backward_over_the_candidate_tiles_gives_the_gradients_of_all_tiles():
+    """Training: the last layer's output is read at the candidate entities' rows only (model.py:177-183), so its epilogue's
+    backward runs over the 32-row tiles of those rows (functional.candidate_tiles) and zero-fills the rest.  Every parameter
+    gradient of a whole step must agree with the step that computes every tile (fp32 tolerance: the weight gradient's
+    partial sums are dealt to the waves differently), and the tile list must be the distinct tiles, ascending, -1 padded."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    t_index = torch.randint(0, 500, (6, 40), generator=gen)
+    t_index[2, 5] = t_index[2, 9]                               # a duplicate candidate
+    tiles = UF.candidate_tiles(t_index.to(dev), 6).cpu()
+    want = torch.unique((t_index * 6 + torch.arange(6).unsqueeze(-1)).reshape(-1) // 32)
+    assert tiles.dtype == torch.int32 and tiles.shape == (240,)
+    assert torch.equal(tiles[:len(want)].long(), want) and (tiles[len(want):] == -1).all()
+    for n_node in (500, 7000, 100000):                          # the one-launch builder (and its density rule)
+        native = UF.candidate_tiles(t_index.to(dev), 6, n_node)
+        if t_index.numel() * 8 > (n_node * 6 + 31) // 32:
+            assert native is None
+        else:
+            assert torch.equal(native.cpu(), tiles)
+    task, triples = _build((1200, 9000, 12))
+    task.num_negative = 32
+    task.to(dev).train()
+    batch = torch.from_numpy(triples[:16]).to(dev)
+    grads = {}
+    for sparse in (True, False):
+        UF.SPARSE_LAST_LAYER_BACKWARD = sparse
+        try:
+            task.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            loss, _ = task(batch)
+            loss.backward()
+            grads[sparse] = {k: p.grad.detach().clone() for k, p in task.named_parameters() if p.grad is not None}
+        finally:
+            UF.SPARSE_LAST_LAYER_BACKWARD = True
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 20
+    for k in grads[True]:
+        scale = grads[False][k].abs().max().item()
+        assert (grads[True][k] - grads[False][k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
+
+
 def test_kept_pre_norm_output_gives_the_gradients_of_the_recomputation():
     """Training forward with z_out (the Linear's output before LayerNorm kept for the backward) against the backward that
     recomputes z: the same bits in every gradient (z is produced by the same fmaf chain), and z itself is the Linear's

@@ -80,6 +80,7 @@ EXPORTS = (
     "ultra_statistics_blocks",
     "ultra_statistics_f32",
     "ultra_bce_adversarial_f32",
+    "ultra_candidate_tiles",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
     "ultra_relcsr_plan_temp_bytes",
@@ -161,6 +162,8 @@ def load():
     lib.ultra_statistics_blocks.argtypes = [i64]
     lib.ultra_statistics_f32.restype = i32
     lib.ultra_statistics_f32.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp]
+    lib.ultra_candidate_tiles.restype = i32
+    lib.ultra_candidate_tiles.argtypes = [vp, i64, i64, i64, i64, vp, vp]
     lib.ultra_bce_adversarial_f32.restype = i32
     lib.ultra_bce_adversarial_f32.argtypes = [vp, i64, i64, ctypes.c_float, vp, vp, vp]
     lib.ultra_relation_stack_inputs.restype = i32
@@ -175,7 +178,7 @@ def load():
     lib.ultra_combine_backward_fused_waves.argtypes = [i32, i64, ctypes.POINTER(i32)]
     lib.ultra_combine_backward_fused_f32.restype = i32
     lib.ultra_combine_backward_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp, vp, vp, vp, vp,
-                                                     vp, vp, sz, i64, i64, vp]
+                                                     vp, vp, sz, vp, i64, i64, i64, vp]
     lib.ultra_linear_forward_f32.restype = i32
     lib.ultra_linear_forward_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.ultra_score_forward_f32.restype = i32

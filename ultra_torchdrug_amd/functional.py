@@ -21,7 +21,7 @@ import torch
 from . import _lib, _torch_ext
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "candidate_tiles", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -728,7 +728,7 @@ class _CombineFunction(torch.autograd.Function):
                     ln_eps, int(relu), int(shortcut), grad_out.data_ptr(), z.data_ptr() if z is not None else None,
                     d_input.data_ptr(), d_update.data_ptr(),
                     d_weight.data_ptr(), d_bias.data_ptr(), d_g.data_ptr() if has_ln else None,
-                    d_b.data_ptr() if has_ln else None, ws.data_ptr(), ws.numel() * 4, rows, 64, _stream()))
+                    d_b.data_ptr() if has_ln else None, ws.data_ptr(), ws.numel() * 4, None, 0, rows, 64, _stream()))
             needs = ctx.needs_input_grad
             return (d_input.view_as(input) if needs[0] else None, d_update.view_as(update) if needs[1] else None,
                     d_weight if needs[2] else None, d_bias if needs[3] else None, d_g if (has_ln and needs[4]) else None,
@@ -838,6 +838,41 @@ class _RSPMMFunction(torch.autograd.Function):
 BOUNDARY_ROWS_BACKWARD = __import__("os").environ.get("ULTRA_BOUNDARY_ROWS_BACKWARD", "1") != "0"
 
 
+# Training, last layer: the epilogue's backward over the candidate rows' tiles only (see sum_layer).  ULTRA_SPARSE_LAST_LAYER=0: all tiles.
+SPARSE_LAST_LAYER_BACKWARD = __import__("os").environ.get("ULTRA_SPARSE_LAST_LAYER", "1") != "0"
+
+
+def candidate_tiles(t_index, n_query, n_node=None):
+    """The 32-row tiles of an ``(N, B, 64)`` activation (rows ``(node, query)``, query fastest) that hold the rows
+    ``(t_index[b, j], b)`` -- where the gradient of ``hidden[t_index, arange(B)]`` (``ultra/model.py:177-183`` with the
+    candidates first, ``model.forward``) is non-zero.  int32 ``(B * K,)``, ascending, ``-1`` padding; static shapes, no host
+    synchronisation (capturable).  ``None`` when the sparse backward is switched off."""
+    if not SPARSE_LAST_LAYER_BACKWARD:
+        return None
+    if n_node is not None:
+        n_rows = int(n_node) * int(n_query)
+        # worth it only where the candidates' tiles are a small part of all tiles (the rest is zero-filled: two passes)
+        if t_index.numel() * 8 > (n_rows + 31) // 32:
+            return None
+        if t_index.is_cuda and t_index.dtype == torch.int64 and t_index.dim() == 2 and n_rows <= (32 << 20):
+            t_index = t_index.contiguous()
+            out = torch.empty(t_index.numel(), dtype=torch.int32, device=t_index.device)
+            lib = _lib.load()
+            with torch.cuda.device(t_index.device):
+                _lib.check(lib.ultra_candidate_tiles(t_index.data_ptr(), t_index.shape[0], t_index.shape[1], int(n_query), n_rows,
+                                                     out.data_ptr(), _stream()))
+            return out
+    rows = t_index.long() * int(n_query) + torch.arange(t_index.shape[0], device=t_index.device).unsqueeze(-1)
+    tiles = torch.div(rows.reshape(-1), 32, rounding_mode="floor")
+    ordered, _ = torch.sort(tiles)
+    first = torch.ones_like(ordered, dtype=torch.bool)
+    first[1:] = ordered[1:] != ordered[:-1]
+    # distinct tiles first (ascending), padding behind: a stable sort on the "duplicate" flag keeps the ascending order
+    keyed = torch.where(first, ordered, torch.full_like(ordered, torch.iinfo(torch.int64).max))
+    keyed, _ = torch.sort(keyed)
+    return torch.where(keyed == torch.iinfo(torch.int64).max, torch.full_like(keyed, -1), keyed).to(torch.int32)
+
+
 class _SumLayerFunction(torch.autograd.Function):
     """One Bellman-Ford layer with summed messages as ONE autograd node:
     ``out = combine(input, rspmm(adjacency, relation, input, sum="add") + boundary)``
@@ -848,7 +883,7 @@ class _SumLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, csr, relation, input, add_rows, b_node, b_value, mul, weight, bias, ln_weight, ln_bias, ln_eps,
-                relu, shortcut, input_is_boundary=False):
+                relu, shortcut, input_is_boundary=False, grad_tiles=None):
         shape = input.shape                                      # (N, B, 64)
         flat = input.flatten(1)
         boundary = None if b_node is None else (b_node, b_value.detach())
@@ -867,6 +902,8 @@ class _SumLayerFunction(torch.autograd.Function):
         ctx.csr, ctx.mul, ctx.b_node, ctx.has_add = csr, mul, b_node, add_rows is not None
         # first layer: `input` is the boundary, whose gradient is consumed at row (b_node[q], q) only
         ctx.boundary_rows_only = bool(input_is_boundary) and b_node is not None and BOUNDARY_ROWS_BACKWARD
+        # last layer: the caller's word that the output's gradient is zero outside these 32-row tiles (see sum_layer)
+        ctx.grad_tiles = grad_tiles if (grad_tiles is not None and SPARSE_LAST_LAYER_BACKWARD) else None
         ctx.flags = (float(ln_eps), bool(relu), bool(shortcut))
         ctx.save_for_backward(relation, input, update, weight, bias, ln_weight, ln_bias, z)
         return out
@@ -877,6 +914,7 @@ class _SumLayerFunction(torch.autograd.Function):
         relation, input, update, weight, bias, ln_weight, ln_bias, z = ctx.saved_tensors
         ln_eps, relu, shortcut = ctx.flags
         needs = ctx.needs_input_grad
+        tiles = ctx.grad_tiles
         shape = input.shape
         dev = input.device
         grad_out = grad_out.contiguous()
@@ -899,7 +937,8 @@ class _SumLayerFunction(torch.autograd.Function):
                 ln_eps, int(relu), int(shortcut), grad_out.data_ptr(), z.data_ptr() if z is not None else None,
                 d_input.data_ptr(), d_update.data_ptr(),
                 d_weight.data_ptr(), d_bias.data_ptr(), d_g.data_ptr() if has_ln else None,
-                d_b.data_ptr() if has_ln else None, ws.data_ptr(), ws.numel() * 4, rows, 64, _stream()))
+                d_b.data_ptr() if has_ln else None, ws.data_ptr(), ws.numel() * 4,
+                tiles.data_ptr() if tiles is not None else None, tiles.numel() if tiles is not None else 0, rows, 64, _stream()))
         # the edge gradient accumulates into the epilogue's d_input (same buffer) inside the rspmm backward
         flat_du = d_update.flatten(1)
         if ctx.boundary_rows_only and needs[2]:
@@ -917,19 +956,23 @@ class _SumLayerFunction(torch.autograd.Function):
             d_value = d_update.view(shape[0], n_query, -1)[ctx.b_node.long(), torch.arange(n_query, device=dev)]
         return (None, d_relation, d_in.view(shape) if d_in is not None else None, d_add, None, d_value, None,
                 d_weight if needs[7] else None, d_bias if needs[8] else None, d_g if (has_ln and needs[9]) else None,
-                d_b if (has_ln and needs[10]) else None, None, None, None, None)
+                d_b if (has_ln and needs[10]) else None, None, None, None, None, None)
 
 
 def sum_layer(csr, relation, input, boundary_dense, boundary_sparse, mul, weight, bias, ln_weight=None, ln_bias=None,
-              ln_eps=1e-5, relu=True, shortcut=False, input_is_boundary=False):
+              ln_eps=1e-5, relu=True, shortcut=False, input_is_boundary=False, grad_tiles=None):
     """A whole sum-aggregation layer for TRAINING as one autograd node (see :class:`_SumLayerFunction`):
     ``[input +] relu(LN(Linear(cat[input, rspmm(csr, relation, input) + boundary])))``.  ``input``: ``(N, B, 64)``;
-    ``relation``: ``(R, B * 64)``; the boundary either dense ``(N, B, 64)`` or sparse ``(node int32 (B,), value (B, 64))``."""
+    ``relation``: ``(R, B * 64)``; the boundary either dense ``(N, B, 64)`` or sparse ``(node int32 (B,), value (B, 64))``.
+    ``input_is_boundary``: the caller's word that ``input`` is the boundary (first layer).  ``grad_tiles``: int32 tile ids
+    (row ``// 32`` of the ``(N * B, 64)`` view, ascending, ``-1`` padding) -- the caller's word that the gradient arriving at
+    this layer's OUTPUT is zero outside those tiles (the last layer, whose output is read at the candidate entities' rows only,
+    ``ultra/model.py:177-183``; see :func:`candidate_tiles`): the epilogue's backward then computes those tiles alone."""
     _check_dense(csr, relation, input.flatten(1))
     b_node, b_value = (None, None) if boundary_sparse is None else boundary_sparse
     add_rows = boundary_dense if boundary_sparse is None else None
     return _SumLayerFunction.apply(csr, relation, input, add_rows, b_node, b_value, mul, weight, bias, ln_weight, ln_bias,
-                                   ln_eps, relu, shortcut, input_is_boundary)
+                                   ln_eps, relu, shortcut, input_is_boundary, grad_tiles)
 
 
 def rspmm_sum_plus(sparse, relation, input, add_rows, mul="mul", boundary=None):

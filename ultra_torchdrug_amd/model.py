@@ -94,7 +94,7 @@ class TransferNBFNet(nn.Module):
         relation = torch.zeros(len(edge_list), 1, dtype=torch.long, device=graph.device)
         return Graph(torch.cat([edge_list, relation], dim=-1), edge_weight, graph.num_node, 1)
 
-    def bellmanford(self, graph, h_index, r_index, separate_grad=False, want_feature=True):
+    def bellmanford(self, graph, h_index, r_index, separate_grad=False, want_feature=True, grad_candidates=None):
         """model.py:101-143.  Returns ``node_feature`` of shape ``(num_node, batch, feature_dim)``; with
         ``want_feature=False`` only its two parts (``hidden``: last layer output, ``query``) -- the fused score
         kernel reads them directly and the ``cat`` of model.py:134-138 is never materialised."""
@@ -115,7 +115,12 @@ class TransferNBFNet(nn.Module):
         graph.relation_tables = self._relation_tables(bs)
         hiddens, step_graphs = [], []
         layer_input = boundary
-        for conv in self.layers:
+        # training: the caller reads the LAST layer's output at rows (grad_candidates[b, j], b) only -- the epilogue's
+        # backward of that layer then works on the tiles of those rows alone (functional.sum_layer)
+        last_tiles = None
+        if grad_candidates is not None and torch.is_grad_enabled() and not want_feature and not separate_grad:
+            last_tiles = backend.get().candidate_tiles(grad_candidates, bs, graph.num_node)
+        for position, conv in enumerate(self.layers):
             step_graph = graph
             if separate_grad:
                 step_graph = graph.clone()
@@ -124,7 +129,8 @@ class TransferNBFNet(nn.Module):
             # the shortcut `hidden + layer_input` (model.py:126-127) is applied inside the layer call
             hidden = conv(step_graph, layer_input,
                           shortcut=self.short_cut and conv.output_dim == layer_input.shape[-1],
-                          input_is_boundary=layer_input is boundary)
+                          input_is_boundary=layer_input is boundary,
+                          grad_tiles=last_tiles if position == len(self.layers) - 1 else None)
             hiddens.append(hidden)
             step_graphs.append(step_graph)
             layer_input = hidden
@@ -311,7 +317,7 @@ class TransferNBFNet(nn.Module):
         if not self.concat_hidden and not self.symmetric:
             # candidates first, concatenation second: the (N, B, 128) node_feature of model.py:134-138 (and, in training,
             # its equally large gradient) is never materialised -- cat([hidden, query])[t] == cat([hidden[t], query])
-            parts = self.bellmanford(graph, h_index[:, 0], r_index[:, 0], want_feature=False)
+            parts = self.bellmanford(graph, h_index[:, 0], r_index[:, 0], want_feature=False, grad_candidates=t_index)
             hidden, query = parts["hidden"], parts["query"]                # (N, B, 64), (B, 64)
             if metric is not None:
                 self._feature_statistics(metric, hidden.detach(), query.detach())
