@@ -365,6 +365,11 @@ int ultra_relation_stack_inputs(const float *const *weights, int64_t n_layers, i
 int ultra_candidate_tiles(const int64_t *t_index, int64_t n_batch, int64_t per_row, int64_t n_query, int64_t n_rows, int32_t *out,
                           void *stream);
 
+/* out[q, :] = rows[node[q], q, :] for rows [n_node, n_query, 64]: the gradient of the boundary VALUES out of a layer's d_update
+ * (backward of the sparse boundary epilogue of ultra_rspmm_forward_boundary_f32; /root/reference/ultra/model.py:106-107's
+ * scatter_add_ backward) in one launch. */
+int ultra_gather_boundary_rows_f32(const float *rows, const int32_t *node, int64_t n_query, float *out, void *stream);
+
 /* Training metrics: norm, mean and unbiased standard deviation of the values { a[0 .. n_a) } together with every b[0 .. n_b)
  * taken b_repeat times, in two launches with double-precision accumulation:  out[0..2] = (norm, mean, std).
  * The reference logs them in every training forward for the relation representations (`query_*`,

@@ -81,6 +81,7 @@ EXPORTS = (
     "ultra_statistics_f32",
     "ultra_bce_adversarial_f32",
     "ultra_candidate_tiles",
+    "ultra_gather_boundary_rows_f32",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
     "ultra_relcsr_plan_temp_bytes",
@@ -162,6 +163,8 @@ def load():
     lib.ultra_statistics_blocks.argtypes = [i64]
     lib.ultra_statistics_f32.restype = i32
     lib.ultra_statistics_f32.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp]
+    lib.ultra_gather_boundary_rows_f32.restype = i32
+    lib.ultra_gather_boundary_rows_f32.argtypes = [vp, vp, i64, vp, vp]
     lib.ultra_candidate_tiles.restype = i32
     lib.ultra_candidate_tiles.argtypes = [vp, i64, i64, i64, i64, vp, vp]
     lib.ultra_bce_adversarial_f32.restype = i32

@@ -953,7 +953,10 @@ class _SumLayerFunction(torch.autograd.Function):
         d_value = None
         if ctx.b_node is not None and needs[5]:
             n_query = ctx.b_node.shape[0]
-            d_value = d_update.view(shape[0], n_query, -1)[ctx.b_node.long(), torch.arange(n_query, device=dev)]
+            d_value = torch.empty(n_query, 64, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.ultra_gather_boundary_rows_f32(d_update.data_ptr(), ctx.b_node.data_ptr(), n_query,
+                                                              d_value.data_ptr(), _stream()))
         return (None, d_relation, d_in.view(shape) if d_in is not None else None, d_add, None, d_value, None,
                 d_weight if needs[7] else None, d_bias if needs[8] else None, d_g if (has_ln and needs[9]) else None,
                 d_b if (has_ln and needs[10]) else None, None, None, None, None, None)
