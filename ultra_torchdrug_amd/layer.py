@@ -67,8 +67,9 @@ class _TallLinear(torch.autograd.Function):
             # the sum over the slices as a (1, s) x (s, out * in) product: ATen's strided `sum(0)` of this shape is a
             # multi-block reduction that zeroes its semaphores with a memset, and a memset NODE inside a captured
             # training step is one more node kind whose replay has misbehaved here (see ultra_rspmm_frontier_f32)
-            ones = torch.ones(1, s, dtype=parts.dtype, device=parts.device)
-            d_weight = (ones @ parts.view(s, -1)).view(parts.shape[1], parts.shape[2])
+            # (as a matrix-VECTOR product: for the (1, s) x (s, out * in) matrix product the BLAS library picks a 47 us kernel)
+            ones = torch.ones(s, dtype=parts.dtype, device=parts.device)
+            d_weight = torch.mv(parts.view(s, -1).t(), ones).view(parts.shape[1], parts.shape[2])
         if ctx.needs_input_grad[2]:          # (a product for the same reason as above)
             d_bias = (torch.ones(1, g.shape[0], dtype=g.dtype, device=g.device) @ g).view(-1)
         return d_input, d_weight, d_bias
