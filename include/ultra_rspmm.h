@@ -370,6 +370,23 @@ int ultra_candidate_tiles(const int64_t *t_index, int64_t n_batch, int64_t per_r
  * scatter_add_ backward) in one launch. */
 int ultra_gather_boundary_rows_f32(const float *rows, const int32_t *node, int64_t n_query, float *out, void *stream);
 
+/* The score head on the candidate rows of a training step, forward and backward (csrc/score_rows.inc):
+ *     score[b, j] = w2 . relu( w1 . cat[ hidden[t_index[b, j], b, :], query[b, :] ] + b1 ) + b2
+ * = /root/reference/ultra/model.py:177-183,193 (gather of the candidate tails, concatenation with the query, the 128 -> 128 -> 1
+ * mlp) with the candidates picked before the concatenation.  hidden [n_node, n_batch, 64], query [n_batch, 64], t_index int64
+ * [n_batch, per_row], w1 [128, 128], b1 [128], w2 [128], b2 [1]; h and in_rows [n_batch * per_row, 128] receive relu(.) and the
+ * gathered cat[.] rows for the backward.  Backward: grad [n_batch, per_row]; scratch d_pre [n_batch * per_row, 128] and partial
+ * [16 * 129 * 129]; d_hidden [n_node, n_batch, 64] is zero-filled and
+ * the candidate rows written (rows repeated inside a query are added in row order); d_query, d_w1, d_b1, d_w2, d_b2 come out
+ * finished, every sum in a fixed order.  per_row <= 160 (the backward keeps a query's rows in LDS). */
+int ultra_score_rows_forward_f32(const float *hidden, const float *query, const int64_t *t_index, const float *w1, const float *b1,
+                                 const float *w2, const float *b2, float *h, float *in_rows, float *score, int64_t n_batch,
+                                 int64_t per_row, void *stream);
+int ultra_score_rows_backward_f32(const float *hidden, const float *query, const int64_t *t_index, const float *w1, const float *w2,
+                                  const float *h, const float *in_rows, const float *grad, float *d_pre, float *partial,
+                                  float *d_hidden, float *d_query, float *d_w1, float *d_b1, float *d_w2, float *d_b2,
+                                  int64_t n_node, int64_t n_batch, int64_t per_row, void *stream);
+
 /* Training metrics: norm, mean and unbiased standard deviation of the values { a[0 .. n_a) } together with every b[0 .. n_b)
  * taken b_repeat times, in two launches with double-precision accumulation:  out[0..2] = (norm, mean, std).
  * The reference logs them in every training forward for the relation representations (`query_*`,

@@ -98,6 +98,18 @@ class OracleFunctional:
         return (loss * neg_weight).sum(dim=-1) / neg_weight.sum(dim=-1)
 
     @staticmethod
+    def score_candidates_supported(hidden, query, t_index, w1, w2):
+        return False                                    # the oracle path scores through the model's own mlp (ATen)
+
+    @staticmethod
+    def score_candidates(hidden, query, t_index, w1, b1, w2, b2):
+        """model.py:177-183,193 as the reference writes it."""
+        rows = torch.arange(hidden.shape[1], device=hidden.device).unsqueeze(-1)
+        feature = torch.cat([hidden[t_index, rows], query.unsqueeze(1).expand(-1, t_index.shape[1], -1)], dim=-1)
+        hid = torch.relu(torch.nn.functional.linear(feature, w1, b1))
+        return torch.nn.functional.linear(hid, w2.view(1, -1), b2).squeeze(-1)
+
+    @staticmethod
     def candidate_tiles(t_index, n_query, n_node=None):
         return None                                     # a hint for the HIP epilogue's backward; the oracle path computes every row
 

@@ -551,6 +551,40 @@ def test_last_layer_backward_over_the_candidate_tiles_gives_the_gradients_of_all
         assert (grads[True][k] - grads[False][k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
 
 
+def test_score_head_on_candidate_rows_matches_the_reference_chain():
+    """ultra_score_rows_* (gather of the candidate rows, concatenation with the query, the 128 -> 128 -> 1 mlp, and the whole
+    backward, as one autograd node) against index + cat + nn.Linear chain in fp64 (ultra/model.py:177-183,193): scores and
+    every gradient, with duplicate candidates inside a query (their rows' gradients add up) and K at the 160-row limit."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    for n_node, batch, cand in [(50, 1, 1), (300, 5, 33), (1200, 16, 129), (400, 3, 160)]:
+        hidden = torch.randn(n_node, batch, 64, generator=gen)
+        query = torch.randn(batch, 64, generator=gen)
+        t_index = torch.randint(0, n_node, (batch, cand), generator=gen)
+        if cand > 8:
+            t_index[0, 5] = t_index[0, 2]
+            t_index[0, 7] = t_index[0, 2]                       # the same node three times in one query
+        l1, l2 = torch.nn.Linear(128, 128), torch.nn.Linear(128, 1)
+        upstream = torch.randn(batch, cand, generator=gen)
+        a = [t.clone().to(dev).requires_grad_() for t in (hidden, query, l1.weight.detach(), l1.bias.detach(), l2.weight.detach(), l2.bias.detach())]
+        b = [t.clone().double().requires_grad_() for t in (hidden, query, l1.weight.detach(), l1.bias.detach(), l2.weight.detach(), l2.bias.detach())]
+        got = UF.score_candidates(a[0], a[1], t_index.to(dev), a[2], a[3], a[4], a[5])
+        rows = torch.arange(batch).unsqueeze(-1)
+        feature = torch.cat([b[0][t_index, rows], b[1].unsqueeze(1).expand(-1, cand, -1)], dim=-1)
+        want = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(feature, b[2], b[3])), b[4], b[5]).squeeze(-1)
+        got.backward(upstream.to(dev))
+        want.backward(upstream.double())
+        torch.testing.assert_close(got.detach().cpu(), want.detach().float(), rtol=2e-5, atol=2e-5)
+        for x, y, name in zip(a, b, ("hidden", "query", "w1", "b1", "w2", "b2")):
+            scale = y.grad.abs().max().item()
+            assert (x.grad.cpu().double() - y.grad).abs().max().item() <= 2e-5 * scale + 1e-7, (name, n_node, batch, cand)
+        # deterministic: a second backward gives the same bits
+        a2 = [t.detach().clone().requires_grad_() for t in a]
+        UF.score_candidates(a2[0], a2[1], t_index.to(dev), a2[2], a2[3], a2[4], a2[5]).backward(upstream.to(dev))
+        assert all(torch.equal(x.grad, y.grad) for x, y in zip(a, a2))
+
+
 def test_kept_pre_norm_output_gives_the_gradients_of_the_recomputation():
     """Training forward with z_out (the Linear's output before LayerNorm kept for the backward) against the backward that
     recomputes z: the same bits in every gradient (z is produced by the same fmaf chain), and z itself is the Linear's

@@ -81,6 +81,8 @@ EXPORTS = (
     "ultra_statistics_f32",
     "ultra_bce_adversarial_f32",
     "ultra_candidate_tiles",
+    "ultra_score_rows_forward_f32",
+    "ultra_score_rows_backward_f32",
     "ultra_gather_boundary_rows_f32",
     "ultra_relcsr_coalesce_temp_bytes",
     "ultra_relcsr_coalesce",
@@ -165,6 +167,10 @@ def load():
     lib.ultra_statistics_f32.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp]
     lib.ultra_gather_boundary_rows_f32.restype = i32
     lib.ultra_gather_boundary_rows_f32.argtypes = [vp, vp, i64, vp, vp]
+    lib.ultra_score_rows_forward_f32.restype = i32
+    lib.ultra_score_rows_forward_f32.argtypes = [vp] * 10 + [i64, i64, vp]
+    lib.ultra_score_rows_backward_f32.restype = i32
+    lib.ultra_score_rows_backward_f32.argtypes = [vp] * 16 + [i64, i64, i64, vp]
     lib.ultra_candidate_tiles.restype = i32
     lib.ultra_candidate_tiles.argtypes = [vp, i64, i64, i64, i64, vp, vp]
     lib.ultra_bce_adversarial_f32.restype = i32

@@ -1833,3 +1833,4 @@ int ultra_combine_forward_boundary_f32(const int32_t *boundary_node, const float
 #include "dense.inc"
 #include "project_bwd.inc"
 #include "sampler.inc"
+#include "score_rows.inc"

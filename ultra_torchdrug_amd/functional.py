@@ -21,7 +21,7 @@ import torch
 from . import _lib, _torch_ext
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "candidate_tiles", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "candidate_tiles", "score_candidates", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -441,6 +441,69 @@ def bce_adversarial_loss(pred, temperature):
     if pred.dim() != 2 or pred.dtype != torch.float32 or not pred.is_cuda:
         raise RuntimeError("bce_adversarial_loss needs fp32 (B, 1 + K) logits on a HIP device (no CPU fallback)")
     return _BCEAdversarial.apply(pred, float(temperature))
+
+
+SCORE_ROWS_MAX_CANDIDATES = 160        # ultra_score_rows_backward_f32 keeps a query's rows in LDS
+
+
+class _ScoreRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hidden, query, t_index, w1, b1, w2, b2):
+        hidden, query, t_index = hidden.contiguous(), query.contiguous(), t_index.contiguous()
+        w1, b1, w2, b2 = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
+        n_batch, per_row = t_index.shape
+        dev = hidden.device
+        h = torch.empty(n_batch * per_row, 128, dtype=torch.float32, device=dev)
+        in_rows = torch.empty(n_batch * per_row, 128, dtype=torch.float32, device=dev)
+        score = torch.empty(n_batch, per_row, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_score_rows_forward_f32(hidden.data_ptr(), query.data_ptr(), t_index.data_ptr(), w1.data_ptr(),
+                                                        b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), h.data_ptr(), in_rows.data_ptr(),
+                                                        score.data_ptr(), n_batch, per_row, _stream()))
+        ctx.save_for_backward(hidden, query, t_index, w1, w2, h, in_rows)
+        return score
+
+    @staticmethod
+    def backward(ctx, grad):
+        hidden, query, t_index, w1, w2, h, in_rows = ctx.saved_tensors
+        n_batch, per_row = t_index.shape
+        dev = hidden.device
+        grad = grad.contiguous()
+        d_pre = torch.empty_like(h)
+        partial = torch.empty(16 * 129 * 129, dtype=torch.float32, device=dev)
+        d_hidden = torch.empty_like(hidden)
+        d_query = torch.empty_like(query)
+        d_w1 = torch.empty(128, 128, dtype=torch.float32, device=dev)
+        d_b1 = torch.empty(128, dtype=torch.float32, device=dev)
+        d_w2 = torch.empty(128, dtype=torch.float32, device=dev)
+        d_b2 = torch.empty(1, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_score_rows_backward_f32(
+                hidden.data_ptr(), query.data_ptr(), t_index.data_ptr(), w1.data_ptr(), w2.data_ptr(), h.data_ptr(), in_rows.data_ptr(),
+                grad.data_ptr(), d_pre.data_ptr(), partial.data_ptr(), d_hidden.data_ptr(), d_query.data_ptr(), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(),
+                d_b2.data_ptr(), hidden.shape[0], n_batch, per_row, _stream()))
+        return d_hidden, d_query, None, d_w1, d_b1, d_w2.view(1, 128), d_b2
+
+
+def score_candidates_supported(hidden, query, t_index, w1, w2):
+    """Shapes :func:`score_candidates` covers: the 64-d model with the 128 -> 128 -> 1 head, at most 160 candidates per query."""
+    return (hidden.is_cuda and hidden.dtype == torch.float32 and hidden.dim() == 3 and hidden.shape[-1] == 64
+            and tuple(query.shape) == (hidden.shape[1], 64) and query.dtype == torch.float32 and t_index.dtype == torch.int64
+            and t_index.dim() == 2 and t_index.shape[0] == hidden.shape[1] and 0 < t_index.shape[1] <= SCORE_ROWS_MAX_CANDIDATES
+            and tuple(w1.shape) == (128, 128) and w2.numel() == 128)
+
+
+def score_candidates(hidden, query, t_index, w1, b1, w2, b2):
+    """Scores ``(B, K)`` of the candidate tails of a training step: ``mlp(cat[hidden[t_index, arange(B)], query])`` with the
+    shipped 128 -> 128 (relu) -> 1 head (``ultra/model.py:177-183,193``), differentiable in ``hidden``, ``query`` and the four
+    parameters -- one forward launch, three backward launches (``ultra_score_rows_*``) instead of an index, a cat, two BLAS
+    products and the ~50 launches of their backward.  ``hidden`` ``(N, B, 64)``, ``query`` ``(B, 64)``, ``t_index`` int64 ``(B, K)``."""
+    if not score_candidates_supported(hidden, query, t_index, w1, w2):
+        raise RuntimeError("score_candidates: (N, B, 64) / (B, 64) fp32 on a HIP device, int64 (B, K <= 160) candidates, "
+                           "a 128 -> 128 -> 1 head")
+    return _ScoreRows.apply(hidden, query, t_index, w1, b1, w2, b2)
 
 
 def relation_stack_inputs(weights, h_index):

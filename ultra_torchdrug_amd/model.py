@@ -8,6 +8,7 @@ from collections.abc import Sequence
 
 import torch
 from torch import nn
+from torch.nn import functional as F
 
 from . import backend, layer
 from .graph import Graph
@@ -321,6 +322,14 @@ class TransferNBFNet(nn.Module):
             hidden, query = parts["hidden"], parts["query"]                # (N, B, 64), (B, 64)
             if metric is not None:
                 self._feature_statistics(metric, hidden.detach(), query.detach())
+            ops = backend.get()
+            head = self.mlp.layers
+            if (len(head) == 2 and self.mlp.activation is F.relu and not self.mlp.short_cut and head[0].bias is not None
+                    and head[1].bias is not None and head[1].out_features == 1
+                    and ops.score_candidates_supported(hidden, query, t_index, head[0].weight, head[1].weight)):
+                # gather + concatenation + mlp (and their backward) as one autograd node over the candidate rows
+                return ops.score_candidates(hidden, query, t_index, head[0].weight, head[0].bias, head[1].weight,
+                                            head[1].bias).view(shape)
             rows = torch.arange(hidden.shape[1], device=hidden.device).unsqueeze(-1)
             feature = torch.cat([hidden[t_index, rows], query.unsqueeze(1).expand(-1, t_index.shape[1], -1)], dim=-1)
             return self.mlp(feature).squeeze(-1).view(shape)
