@@ -36,11 +36,16 @@ def auto_sizes(n_edges, wide=False):
     fix-up traffic and longer runs of the branch-free batch path, but every 16-lane group of the quad kernel (four
     chunks per wave, 2 048 groups share a column tile on an MI355X) needs a few chunks to stay busy.  Measured best
     (tools/kbench.py --chunk --piece, forward / backward): S-codexs (66 k edges) and S-wn18rr (174 k) 32 / 128,
-    S-fb15k237 (544 k) 32 / 256.  ``wide``: node ids do not fit the packed word (one chunk per wave, kernel
-    variants 2 / 3): 128 / 512."""
+    S-fb15k237 (544 k) 128 / 256 (round 3, with a label's column tiles side by side: forward 243 -> 235 us, evaluation batch
+    2.40 -> 2.38 ms against 32 / 256; fine-tuning steps unchanged).  ``wide``: node ids do not fit the packed word (one chunk
+    per wave, kernel variants 2 / 3): 128 / 512.  ``ULTRA_CHUNK_EDGES`` overrides the chunk size (experiments)."""
     if wide:
         return 128, 512
-    return (32, 256) if n_edges >= 300_000 else (32, 128)
+    import os
+    forced = os.environ.get("ULTRA_CHUNK_EDGES")            # experiments (tools/kbench.py has --chunk for single kernels)
+    if n_edges >= 300_000:
+        return (int(forced) if forced else 128), 256
+    return (int(forced) if forced else 32), 128
 
 
 CHUNK_EDGES, PIECE_LEN = auto_sizes(0)    # the sizes small graphs get (kept as names for explicit callers / tests)
