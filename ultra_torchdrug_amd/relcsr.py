@@ -31,21 +31,28 @@ from . import _lib
 CHUNK_ROWS = 64      # at most this many rows per chunk (bounds the work of runs of empty rows)
 
 
-def auto_sizes(n_edges, wide=False):
+def auto_sizes(n_edges, wide=False, n_rows=None):
     """(chunk_edges, piece_len) for a graph with ``n_edges`` coalesced edges.  Bigger chunks mean fewer pieces, less
     fix-up traffic and longer runs of the branch-free batch path, but every 16-lane group of the quad kernel (four
     chunks per wave, 2 048 groups share a column tile on an MI355X) needs a few chunks to stay busy.  Measured best
     (tools/kbench.py --chunk --piece, forward / backward): S-codexs (66 k edges) and S-wn18rr (174 k) 32 / 128,
-    S-fb15k237 (544 k) 128 / 256 (round 3, with a label's column tiles side by side: forward 243 -> 235 us, evaluation batch
-    2.40 -> 2.38 ms against 32 / 256; fine-tuning steps unchanged).  ``wide``: node ids do not fit the packed word (one chunk
+    S-fb15k237 (544 k) 128 / 512 (round 3, with a label's column tiles side by side: evaluation batch 2.40 -> 2.38 ms with
+    128-edge chunks, -> 2.36 ms with 512-edge pieces; 1 024-edge pieces: 2.345 ms, but the fine-tuning step 6.88 -> 7.28 ms
+    through the relation-major d_relation plan, whose rows are long; fine-tuning steps unchanged at 512).  Graphs of few,
+    very long rows (relation graphs) keep 256: 512 there cost the evaluation batch 80 us.  ``wide``: node ids do not fit the packed word (one chunk
     per wave, kernel variants 2 / 3): 128 / 512.  ``ULTRA_CHUNK_EDGES`` overrides the chunk size (experiments)."""
     if wide:
         return 128, 512
     import os
     forced = os.environ.get("ULTRA_CHUNK_EDGES")            # experiments (tools/kbench.py has --chunk for single kernels)
+    piece = os.environ.get("ULTRA_PIECE_LEN")
     if n_edges >= 300_000:
-        return (int(forced) if forced else 128), 256
-    return (int(forced) if forced else 32), 128
+        # graphs of few, very long rows (a relation graph: 474 rows of 1 896 edges) keep short pieces -- they ARE the work
+        # items; entity graphs split only their hubs and take long ones (ULTRA_BIG_PIECE, experiments)
+        dense_rows = n_rows is not None and n_edges >= 512 * max(int(n_rows), 1)
+        big = int(os.environ.get("ULTRA_BIG_PIECE", "512"))
+        return (int(forced) if forced else 128), (int(piece) if piece else (256 if dense_rows else big))
+    return (int(forced) if forced else 32), (int(piece) if piece else 128)
 
 
 CHUNK_EDGES, PIECE_LEN = auto_sizes(0)    # the sizes small graphs get (kept as names for explicit callers / tests)
@@ -350,7 +357,7 @@ class RelCSR:
         # chunk / piece sizes: explicit, or chosen from the coalesced edge count; ONE pair for all three plans, and
         # `piece_len` is the summation-order parameter the oracle needs (oracle `piece`)
         wide = wide_ids or 8 + max((n_rel - 1).bit_length(), 1) + max((max(n_dst, n_src) - 1).bit_length(), 1) > 32
-        auto_chunk, auto_piece = auto_sizes(self.n_edges, wide)
+        auto_chunk, auto_piece = auto_sizes(self.n_edges, wide, n_dst)
         self.chunk_edges = int(self._requested[0] or auto_chunk)
         self.piece_len = int(self._requested[1] or (auto_piece if self._requested[0] is None else 4 * self.chunk_edges))
         self._opts.update(chunk_edges=self.chunk_edges, piece_len=self.piece_len)
