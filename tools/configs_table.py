@@ -14,6 +14,8 @@ def main(path, out):
             got = ("predict %.3f ms per batch; entity forward kernel %.1f us = %.1f TB/s algorithmic (%.2f of the XCD-L2 peak)"
                    % (c["predict_ms_per_batch"], c["entity_fwd_kernel_us"], c["entity_fwd_kernel_algorithmic_GBps"] / 1e3,
                       c["entity_fwd_kernel_frac_of_l2_peak"]))
+            if "entity_fwd_kernel_us_one_side_width" in c:
+                got += "; %.1f us at one side's width (F = B * 64)" % c["entity_fwd_kernel_us_one_side_width"]
         elif k == 3:
             s = c["finetune_step"]
             got = ("operator fwd %.1f us, bwd %.1f us; fine-tune step median %.2f ms (p10 %.2f, p90 %.2f, max %.2f; n = %d)"
