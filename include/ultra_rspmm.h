@@ -361,7 +361,8 @@ int ultra_relation_stack_inputs(const float *const *weights, int64_t n_layers, i
 /* Training, last layer: the distinct 32-row tiles (row / 32) of an [n_rows = N * n_query, 64] activation that hold the rows
  * (t_index[b, j] * n_query + b) -- where the gradient of hidden[t_index, arange(B)] (/root/reference/ultra/model.py:177-183) is
  * non-zero -- ascending, -1 padded to n_batch * per_row entries, in one launch: the tile_list of
- * ultra_combine_backward_fused_f32.  n_rows <= 32 Mi (ULTRA_ERR_BAD_SHAPE above: the caller builds the list itself). */
+ * ultra_combine_backward_fused_f32.  n_rows <= 32 Mi (ULTRA_ERR_BAD_SHAPE above: the caller builds the list itself); t_index
+ * entries in [0, n_rows / n_query), unchecked. */
 int ultra_candidate_tiles(const int64_t *t_index, int64_t n_batch, int64_t per_row, int64_t n_query, int64_t n_rows, int32_t *out,
                           void *stream);
 
@@ -378,7 +379,9 @@ int ultra_gather_boundary_rows_f32(const float *rows, const int32_t *node, int64
  * gathered cat[.] rows for the backward.  Backward: grad [n_batch, per_row]; scratch d_pre [n_batch * per_row, 128] and partial
  * [16 * 129 * 129]; d_hidden [n_node, n_batch, 64] is zero-filled and
  * the candidate rows written (rows repeated inside a query are added in row order); d_query, d_w1, d_b1, d_w2, d_b2 come out
- * finished, every sum in a fixed order.  per_row <= 160 (the backward keeps a query's rows in LDS). */
+ * finished, every sum in a fixed order.  per_row <= 160 (the backward keeps a query's rows in LDS).  t_index entries must lie
+ * in [0, n_node): like the reference's gather they are not checked on the device (engine.validate_triples and the strict
+ * negative sampler guarantee it). */
 int ultra_score_rows_forward_f32(const float *hidden, const float *query, const int64_t *t_index, const float *w1, const float *b1,
                                  const float *w2, const float *b2, float *h, float *in_rows, float *score, int64_t n_batch,
                                  int64_t per_row, void *stream);
