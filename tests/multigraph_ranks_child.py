@@ -1,0 +1,85 @@
+"""Child process of tests/test_configs_gpu.py::test_multi_graph_graphed_steps_on_two_ranks_that_draw_different_graphs (not a
+test module itself): ONE rank of a two-rank job in which the ranks train on DIFFERENT graphs in most steps and meet each graph
+for the first time on different steps (multi-graph pre-training, /root/reference/ultra/engine.py:23-34).
+
+    python multigraph_ranks_child.py RANK WORLD PORT BACKEND
+
+BACKEND gloo: both ranks share cuda:0 (a one-GPU box; gloo reduces CUDA tensors through the host); nccl: one GPU per rank.
+Runs the same hop sequence twice -- engine.GraphedMultiGraphTrainStep with a GradientReducer, then eager engine.train_step
+with a reducer on the negatives the replays drew -- and prints one JSON line: bucket all-reduces per step, whether graphed and
+eager parameters are equal, and a checksum of the final parameters (the parent compares the ranks')."""
+import copy
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+# rank 0 and rank 1 meet each graph for the first time on different steps, and share a graph on one step only
+ORDERS = (["fb15k237", "fb15k237", "wn18rr", "codexm", "wn18rr", "fb15k237"],
+          ["codexm", "wn18rr", "wn18rr", "fb15k237", "codexm", "fb15k237"])
+
+
+def main():
+    rank, world, port, backend = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    kwargs = dict(device_id=dev) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, **kwargs)
+    from test_configs_gpu import _multi_graph_task
+    from ultra_torchdrug_amd import engine
+    B = 16
+    task = _multi_graph_task(scale=8, num_negative=32).to(dev).train()          # same seed: same weights on both ranks
+    state = copy.deepcopy(task.state_dict())
+    twin = _multi_graph_task(scale=8, num_negative=32).to(dev).train()
+    twin.load_state_dict(state)
+    gen = torch.Generator().manual_seed(100 + rank)                              # per-rank draws (script/run_full.py:102-107)
+    batches = []
+    for gid in ORDERS[rank % len(ORDERS)]:
+        fact = task.contexts[gid]["fact_graph"].edge_list
+        batches.append((fact[torch.randperm(len(fact), generator=gen)[:B].to(dev)], gid))
+
+    opt_g = torch.optim.AdamW(twin.parameters(), lr=1e-3)
+    reducer_g = engine.GradientReducer(twin, overlap=True)
+    graphed = engine.GraphedMultiGraphTrainStep(twin, opt_g, B, reducer=reducer_g)
+    after_init = reducer_g.total_launched
+    per_step, negatives, losses_g = [], [], []
+    for batch in batches:
+        before = reducer_g.total_launched
+        loss, _ = graphed(batch)
+        per_step.append(reducer_g.total_launched - before)
+        negatives.append(graphed.steps[batch[1]].last_negatives.clone())
+        losses_g.append(float(loss))
+    torch.cuda.synchronize()
+
+    opt_e = torch.optim.AdamW(task.parameters(), lr=1e-3)
+    reducer_e = engine.GradientReducer(task, overlap=True)
+    losses_e = []
+    for batch, neg in zip(batches, negatives):
+        task._static_negative = neg
+        loss, _ = engine.train_step(task, opt_e, batch, reducer=reducer_e)
+        losses_e.append(float(loss))
+    task._static_negative = None
+    torch.cuda.synchronize()
+    equal = all(torch.equal(a, b) for a, b in zip(task.parameters(), twin.parameters()))
+    flat = torch.cat([p.detach().reshape(-1).double() for p in twin.parameters()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    print(json.dumps({"rank": rank, "buckets": len(reducer_g.buckets), "warm_launches": after_init, "per_step": per_step,
+                      "captured": sorted(graphed.steps), "graphed_equals_eager": equal, "losses_equal": losses_g == losses_e,
+                      "ranks_hold_equal_parameters": bool(all(torch.equal(both[0], b) for b in both[1:])),
+                      "finite": bool(torch.isfinite(flat).all())}), flush=True)
+    reducer_g.remove_hooks()
+    reducer_e.remove_hooks()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

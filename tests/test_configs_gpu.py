@@ -266,3 +266,95 @@ def test_multi_graph_graphed_steps_equal_eager_steps():
     assert set(graphed.steps) == set(PRETRAIN_3G)
     for (k, a), (_, b) in zip(task.named_parameters(), twin.named_parameters()):
         assert torch.equal(a, b), k
+
+
+def test_multi_graph_graphed_steps_send_one_round_of_buckets_per_step_over_rccl():
+    """Config 4's fastest mode WITH the gradient reducer on the real backend (a one-rank `nccl` = RCCL group): every context
+    is captured in the constructor with the hooks paused -- the only collectives of the constructor are the ``warm()`` round
+    -- and every call, first uses of a graph and ragged eager batches included, sends exactly one all-reduce per bucket
+    (round 3 captured lazily with live hooks, `warmup` extra rounds on the rank that met a graph first).
+    Parameters after the hop sequence equal those of eager steps with a reducer on the same negatives."""
+    import copy
+    import os
+    import torch.distributed as dist
+    from ultra_torchdrug_amd import engine
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    dev = _dev()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=dev)
+    try:
+        task = _multi_graph_task(scale=8, num_negative=32).to(dev).train()
+        state = copy.deepcopy(task.state_dict())
+        twin = _multi_graph_task(scale=8, num_negative=32).to(dev).train()
+        twin.load_state_dict(state)
+        gen = torch.Generator().manual_seed(17)
+        order = [("wn18rr", 16), ("fb15k237", 16), ("wn18rr", 16), ("codexm", 9), ("codexm", 16), ("fb15k237", 16)]   # 9: ragged
+        batches = []
+        for gid, n in order:
+            fact = task.contexts[gid]["fact_graph"].edge_list
+            batches.append((fact[torch.randperm(len(fact), generator=gen)[:n].to(dev)], gid))
+        opt_g = torch.optim.AdamW(twin.parameters(), lr=1e-3)
+        reducer = engine.GradientReducer(twin, overlap=True, single_rank=True)
+        graphed = engine.GraphedMultiGraphTrainStep(twin, opt_g, 16, reducer=reducer)
+        n_buckets = len(reducer.buckets)
+        assert set(graphed.steps) == set(PRETRAIN_3G)                       # all captured up front, none lazily
+        assert reducer.total_launched == n_buckets and reducer.rounds == 0  # the constructor: warm() and nothing else
+        negatives = []
+        for batch in batches:
+            before, rounds = reducer.total_launched, reducer.rounds
+            torch.manual_seed(len(negatives))                               # (the ragged eager step draws with torch.rand)
+            graphed(batch)
+            assert reducer.total_launched - before == n_buckets and reducer.rounds == rounds + 1, batch[1]
+            step = graphed.steps[batch[1]] if len(batch[0]) == 16 else twin      # a replay rewrites ITS capture's tensor
+            negatives.append(step.last_negatives.clone())
+        torch.cuda.synchronize()
+        opt_e = torch.optim.AdamW(task.parameters(), lr=1e-3)
+        reducer_e = engine.GradientReducer(task, overlap=True, single_rank=True)
+        for batch, neg in zip(batches, negatives):
+            task._static_negative = neg
+            engine.train_step(task, opt_e, batch, reducer=reducer_e)
+        task._static_negative = None
+        for (k, a), (_, b) in zip(task.named_parameters(), twin.named_parameters()):
+            assert torch.equal(a, b), k
+        reducer.remove_hooks()
+        reducer_e.remove_hooks()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multi_graph_graphed_steps_on_two_ranks_that_draw_different_graphs():
+    """TWO ranks (child processes; they share this box's GPU over gloo, one GPU each over RCCL where two are visible) run
+    config 4's graphed step with a reducer while drawing DIFFERENT graphs -- each rank meets each graph for the first time on
+    another step.  The job must finish (no diverging collective sequences: round 3's lazy capture paired one rank's warm-up
+    rounds with the other's gradients and hung at the end), both ranks must hold the same parameters, every step must have
+    sent one round of buckets, and the graphed steps must equal eager reducer steps on the same negatives."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multigraph_ranks_child.py")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, child, str(r), "2", str(port), backend], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    reports = []
+    try:
+        for proc in procs:
+            out, err = proc.communicate(timeout=900)
+            lines = [line for line in out.splitlines() if line.startswith("{")]
+            assert proc.returncode == 0 and lines, "rank failed (rc %s): %s" % (proc.returncode, err[-2000:])
+            reports.append(json.loads(lines[-1]))
+    finally:
+        for proc in procs:                      # a hang is the failure this test exists for: end exactly these two
+            if proc.poll() is None:
+                proc.kill()
+    for rep in reports:
+        assert rep["captured"] == sorted(PRETRAIN_3G), rep
+        assert rep["warm_launches"] == rep["buckets"], rep                  # constructor: one warm round only
+        assert rep["per_step"] == [rep["buckets"]] * len(rep["per_step"]), rep
+        assert rep["graphed_equals_eager"] and rep["losses_equal"] and rep["ranks_hold_equal_parameters"] and rep["finite"], rep

@@ -129,6 +129,28 @@ def _worker(rank, world, port, out_dir):
     with oracle_rspmm(0):
         mean, per_graph, rankings = engine.evaluate_all(multi, sets, batch_size=8)
     assert multi.split == "default" and rankings["default"].shape == (21, 2) and rankings["second"].shape == (13, 2)
+
+    # multi-graph TRAINING with the ranks on different graphs in the same step (ultra/engine.py:23-34: every rank draws its
+    # own graph): with a reducer every step sends one round of buckets in bucket order whatever graph a rank is on, so the
+    # sequences of collectives agree and both ranks end with the same parameters; warm() is one more round, nothing else
+    multi.train()
+    opt_m = torch.optim.AdamW(multi.parameters(), lr=5e-4)
+    reducer = engine.GradientReducer(multi, overlap=True)
+    assert reducer.warm() == len(reducer.buckets) and reducer.total_launched == len(reducer.buckets) and reducer.rounds == 0
+    hops = (["default", "second", "second", "default"], ["second", "second", "default", "default"])[rank]
+    pools = {"default": triples, "second": torch.from_numpy(other)}
+    with oracle_rspmm(0):
+        for s, gid in enumerate(hops):
+            before = reducer.total_launched
+            multi._static_negative = torch.randint(0, 90, (8, 8), generator=torch.Generator().manual_seed(31 * s + rank))
+            engine.train_step(multi, opt_m, (pools[gid][50 * s + 8 * rank: 50 * s + 8 * rank + 8], gid), reducer=reducer)
+            assert reducer.total_launched - before == len(reducer.buckets) and reducer.rounds == s + 1
+    multi._static_negative = None
+    reducer.remove_hooks()
+    hop_params = torch.cat([p.detach().reshape(-1) for p in multi.parameters()])
+    hop_both = [torch.zeros_like(hop_params) for _ in range(world)]
+    dist.all_gather(hop_both, hop_params)
+    assert torch.equal(hop_both[0], hop_both[1]) and torch.isfinite(hop_params).all()
     torch.save(dict(ranking=ranking, mrr=metric["mrr"], loss=loss, tloss=tmetric["binary cross entropy"],
                     unused=unused, grads=grads, multi_mean=mean, multi_rankings=rankings,
                     multi_mrr={k: float(v["mrr"]) for k, v in per_graph.items()}),
