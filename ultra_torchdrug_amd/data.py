@@ -83,3 +83,48 @@ def load_triples(path, entity_vocab=None, relation_vocab=None):
             rows.append((entity_vocab.setdefault(h, len(entity_vocab)), entity_vocab.setdefault(t, len(entity_vocab)),
                          relation_vocab.setdefault(r, len(relation_vocab))))
     return np.asarray(rows, dtype=np.int64).reshape(-1, 3), entity_vocab, relation_vocab
+
+
+SPLIT_FILES = ("train.txt", "valid.txt", "test.txt")
+
+
+def load_split_dir(path):
+    """A transductive dataset directory in the reference's layout (``ultra/dataset.py:33-66``): ``train.txt``, ``valid.txt``
+    and ``test.txt`` of ``h<TAB>r<TAB>t`` lines, ONE entity / relation vocabulary built in that order (``build_vocab`` reads
+    the three files one after the other with shared dictionaries).  Returns ``(triples (T, 3) int64 rows of (h, t, r) = train +
+    valid + test concatenated, counts [n_train, n_valid, n_test], num_node, num_relation)`` -- what ``self.triplets`` /
+    ``self.num_samples`` hold there."""
+    path = os.path.expanduser(path)
+    entity_vocab, relation_vocab = {}, {}
+    parts = []
+    for name in SPLIT_FILES:
+        file = os.path.join(path, name)
+        if not os.path.isfile(file):
+            raise FileNotFoundError("%s: a transductive split directory holds %s" % (file, ", ".join(SPLIT_FILES)))
+        rows, entity_vocab, relation_vocab = load_triples(file, entity_vocab, relation_vocab)
+        parts.append(rows)
+    return np.concatenate(parts), [len(p) for p in parts], len(entity_vocab), len(relation_vocab)
+
+
+def task_from_split_dir(path, checkpoint=None, device="cpu", **task_kwargs):
+    """The shipped 6 x 64d Ultra over a real split directory: the train triples carry messages, valid + test belong to the
+    filter graph (``ultra/task.py:31-63``), weights from ``checkpoint`` (``td_ultra_3g.pth`` / ``td_ultra_4g.pth`` layout,
+    ``ultra/util.py:233-276``) or seeded random init.  Returns ``(task in eval mode on device, splits)`` with
+    ``splits = {"train" | "valid" | "test": (n, 3) tensors}``."""
+    from .checkpoint import load_checkpoint
+    from .task import build_ultra
+    triples, counts, n_node, n_rel = load_split_dir(path)
+    triples = torch.from_numpy(triples)
+    fact_mask = torch.zeros(len(triples), dtype=torch.bool)
+    fact_mask[:counts[0]] = True
+    torch.manual_seed(DEFAULT_SEED)
+    task = build_ultra(n_rel, **task_kwargs)
+    missing = unexpected = None
+    if checkpoint is not None:
+        missing, unexpected = load_checkpoint(task, checkpoint, map_location="cpu")
+    task.preprocess(Graph(triples, num_node=n_node, num_relation=n_rel), fact_mask)
+    task.to(device).eval()
+    bounds = np.cumsum([0] + counts)
+    splits = {name.split(".")[0]: triples[bounds[i]:bounds[i + 1]] for i, name in enumerate(SPLIT_FILES)}
+    task.checkpoint_keys = (missing, unexpected)
+    return task, splits

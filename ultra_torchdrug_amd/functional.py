@@ -461,18 +461,21 @@ class _ScoreRows(torch.autograd.Function):
             _lib.check(lib.ultra_score_rows_forward_f32(hidden.data_ptr(), query.data_ptr(), t_index.data_ptr(), w1.data_ptr(),
                                                         b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), h.data_ptr(), in_rows.data_ptr(),
                                                         score.data_ptr(), n_batch, per_row, _stream()))
-        ctx.save_for_backward(hidden, query, t_index, w1, w2, h, in_rows)
+        # the backward never reads `hidden` (its rows are in `in_rows`): only the shape is kept, so the step's largest
+        # activation is not held alive until the score head's backward
+        ctx.hidden_shape = tuple(hidden.shape)
+        ctx.save_for_backward(query, t_index, w1, w2, h, in_rows)
         return score
 
     @staticmethod
     def backward(ctx, grad):
-        hidden, query, t_index, w1, w2, h, in_rows = ctx.saved_tensors
+        query, t_index, w1, w2, h, in_rows = ctx.saved_tensors
         n_batch, per_row = t_index.shape
-        dev = hidden.device
+        dev = query.device
         grad = grad.contiguous()
         d_pre = torch.empty_like(h)
         partial = torch.empty(16 * 129 * 129, dtype=torch.float32, device=dev)
-        d_hidden = torch.empty_like(hidden)
+        d_hidden = torch.empty(ctx.hidden_shape, dtype=torch.float32, device=dev)
         d_query = torch.empty_like(query)
         d_w1 = torch.empty(128, 128, dtype=torch.float32, device=dev)
         d_b1 = torch.empty(128, dtype=torch.float32, device=dev)
@@ -481,9 +484,9 @@ class _ScoreRows(torch.autograd.Function):
         lib = _lib.load()
         with torch.cuda.device(dev):
             _lib.check(lib.ultra_score_rows_backward_f32(
-                hidden.data_ptr(), query.data_ptr(), t_index.data_ptr(), w1.data_ptr(), w2.data_ptr(), h.data_ptr(), in_rows.data_ptr(),
+                None, query.data_ptr(), t_index.data_ptr(), w1.data_ptr(), w2.data_ptr(), h.data_ptr(), in_rows.data_ptr(),
                 grad.data_ptr(), d_pre.data_ptr(), partial.data_ptr(), d_hidden.data_ptr(), d_query.data_ptr(), d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(),
-                d_b2.data_ptr(), hidden.shape[0], n_batch, per_row, _stream()))
+                d_b2.data_ptr(), ctx.hidden_shape[0], n_batch, per_row, _stream()))
         return d_hidden, d_query, None, d_w1, d_b1, d_w2.view(1, 128), d_b2
 
 
@@ -950,9 +953,13 @@ class _SumLayerFunction(torch.autograd.Function):
         shape = input.shape                                      # (N, B, 64)
         flat = input.flatten(1)
         boundary = None if b_node is None else (b_node, b_value.detach())
-        if (input_is_boundary and boundary is not None and BOUNDARY_ROWS_BACKWARD and frontier_supported("add", mul, flat.shape[1])
-                and csr.shape[0] == csr.shape[1]
-                and (torch.cuda.is_current_stream_capturing() or bool(torch.isfinite(relation).all()))):
+        # what BOTH first-layer shortcuts need (frontier forward, boundary-rows backward): the caller's promise, a square
+        # adjacency, one 64-column block per query, a query count the backward's grid can take -- decided HERE, so that a
+        # layer outside those limits takes the full kernels in both directions instead of failing in backward
+        first_layer = bool(input_is_boundary and boundary is not None and BOUNDARY_ROWS_BACKWARD
+                           and frontier_supported("add", mul, flat.shape[1]) and csr.shape[0] == csr.shape[1]
+                           and flat.shape[1] == 64 * b_node.shape[0] and b_node.shape[0] <= 65535)
+        if first_layer and (torch.cuda.is_current_stream_capturing() or bool(torch.isfinite(relation).all())):
             # first layer: only the boundary nodes' out-edges carry a message (same bits as the full kernel, finite tables:
             # see rspmm_frontier) -- as in inference
             update = rspmm_frontier(csr, relation.detach(), boundary)
@@ -964,7 +971,7 @@ class _SumLayerFunction(torch.autograd.Function):
         out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut, z_out=z)
         ctx.csr, ctx.mul, ctx.b_node, ctx.has_add = csr, mul, b_node, add_rows is not None
         # first layer: `input` is the boundary, whose gradient is consumed at row (b_node[q], q) only
-        ctx.boundary_rows_only = bool(input_is_boundary) and b_node is not None and BOUNDARY_ROWS_BACKWARD
+        ctx.boundary_rows_only = first_layer
         # last layer: the caller's word that the output's gradient is zero outside these 32-row tiles (see sum_layer)
         ctx.grad_tiles = grad_tiles if (grad_tiles is not None and SPARSE_LAST_LAYER_BACKWARD) else None
         ctx.flags = (float(ln_eps), bool(relu), bool(shortcut))

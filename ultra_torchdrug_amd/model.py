@@ -309,6 +309,17 @@ class TransferNBFNet(nn.Module):
         if self.check_indices:      # two host syncs per call (model.py:174-175); engine.GraphedPredict turns them
             assert (h_index[:, [0]] == h_index).all()       # off while a hipGraph is captured / replayed
             assert (r_index[:, [0]] == r_index).all()
+            # the fused kernels index with these ids without a bounds check of their own (frontier: src_ptr[h]; candidate
+            # tiles: an LDS bitmap at (t, b); score rows: hidden[t, b] read, d_hidden[t, b] written): an id from another
+            # split's vocabulary fails in an ATen index kernel in the reference and must fail HERE, not corrupt memory
+            # (ADVICE r3); captured steps validate their batches once instead (engine.validate_triples)
+            n_node, n_rel = graph.num_node, max(graph.num_relation, 1)
+            bad = ((h_index < 0) | (h_index >= n_node) | (t_index < 0) | (t_index >= n_node)
+                   | (r_index < 0) | (r_index >= n_rel)).any()
+            if bool(bad):
+                raise IndexError("entity ids must lie in [0, %d) and relation ids in [0, %d): got h in [%d, %d], t in [%d, %d], "
+                                 "r in [%d, %d]" % (n_node, n_rel, int(h_index.min()), int(h_index.max()), int(t_index.min()),
+                                                    int(t_index.max()), int(r_index.min()), int(r_index.max())))
         if all_entities and self._fused_score_ok(graph, t_index, metric):
             parts = self.bellmanford(graph, h_index[:, 0], r_index[:, 0], want_feature=False)
             first, second = self.mlp.layers
