@@ -285,3 +285,59 @@ def test_eager_forward_refuses_ids_outside_the_graph():
     task._static_negative = neg
     loss, _ = task(batch)
     assert torch.isfinite(loss)
+
+
+def test_cpu_path_equals_the_aten_definition_of_the_reference():
+    """The product's CPU kernels against the reference's OWN O(E) definition of the operator (``message`` + ``aggregate``,
+    /root/reference/ultra/layer.py:232-296) with every other operator of the stack in ATen too (tests/aten_definition.py) -- no
+    C oracle on either side.  A whole evaluation batch and a whole training step; the definition in fp64 is the truth, and the
+    product path must be as close to it as the definition in fp32 is."""
+    from aten_definition import aten_definition
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.task import build_ultra
+    triples, n, r = synthetic_triples((150, 900, 5), 3)
+    mask = np.zeros(len(triples), dtype=bool)
+    mask[:800] = True
+    torch.manual_seed(3)
+    task = build_ultra(r, num_negative=8)
+    task.preprocess(Graph(torch.from_numpy(triples), num_node=n, num_relation=r), torch.from_numpy(mask)).eval()
+    tr = torch.from_numpy(triples)
+    batch = tr[800:816]
+    with torch.no_grad():
+        pred = task.predict(batch)
+        rank = task.rank_batch(batch, pred=pred)
+        with aten_definition(task):
+            pred_aten = task.predict(batch)
+        with aten_definition(task, double=True):
+            pred_true = task.predict(batch)
+            rank_true = task.get_ranking(pred_true, task.target(batch))
+    assert pred_true.dtype == torch.float64 and all(p.dtype == torch.float32 for p in task.parameters())
+    scale = pred_true.abs().max().item()
+    e, e_aten = (pred.double() - pred_true).abs().max().item(), (pred_aten.double() - pred_true).abs().max().item()
+    assert e <= 4 * e_aten + 1e-5 * scale and (rank == rank_true).float().mean() > 0.9
+
+    task.train()
+    b = tr[:8]
+    neg = task._strict_negative(*b.t())
+
+    def step():
+        task.zero_grad(set_to_none=True)
+        task._static_negative = neg
+        try:
+            loss, _ = task(b)
+            loss.backward()
+        finally:
+            task._static_negative = None
+        return float(loss), {k: p.grad.double().clone() for k, p in task.named_parameters() if p.grad is not None}
+    loss, g = step()
+    with aten_definition(task):
+        loss_aten, g_aten = step()
+    with aten_definition(task, double=True):
+        loss_true, g_true = step()
+    assert g.keys() == g_aten.keys() == g_true.keys() and len(g_true) == 82
+    assert abs(loss - loss_true) <= 4 * abs(loss_aten - loss_true) + 1e-5 * abs(loss_true)
+    for k in g_true:
+        s = g_true[k].abs().max().item() + 1e-12
+        e, e_aten = (g[k] - g_true[k]).abs().max().item(), (g_aten[k] - g_true[k]).abs().max().item()
+        assert e <= 4 * e_aten + 1e-4 * s, (k, e, e_aten, s)

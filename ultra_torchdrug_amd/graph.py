@@ -54,12 +54,12 @@ class Graph:
     @property
     def degree_out(self):
         """Weighted number of edges that have each node as ``node_out`` (torchdrug's naming)."""
-        out = torch.zeros(self.num_node, device=self.device)
+        out = torch.zeros(self.num_node, device=self.device, dtype=self.edge_weight.dtype)
         return out.index_add_(0, self.edge_list[:, 1], self.edge_weight)
 
     @property
     def degree_in(self):
-        out = torch.zeros(self.num_node, device=self.device)
+        out = torch.zeros(self.num_node, device=self.device, dtype=self.edge_weight.dtype)
         return out.index_add_(0, self.edge_list[:, 0], self.edge_weight)
 
     @property
