@@ -595,10 +595,12 @@ def pretrain_timing(dev, seed, rank, world, ranks, quick):
         loop(same[:3], True)
         with_comm, _, _ = loop(same, True)
         without, _, _ = loop(same, False)                            # LAST: the ranks' weights drift apart from here on
-        out.update({"gradient_allreduce": "engine.GradientReducer: %d buckets, %d fp32 parameters, %s, side stream, after each "
-                                          "replay; + 1 packed metric all-reduce" % (len(reducer.buckets),
-                                                                                     sum(b["numel"] for b in reducer.buckets),
-                                                                                     dist.get_backend()),
+        mode = next(iter(graphed.steps.values())).mode
+        out.update({"gradient_allreduce": "engine.GradientReducer: %d buckets, %d fp32 parameters, %s, side stream; step mode `%s` "
+                                          "(phased: 3 captured phases, each phase's buckets all-reduced while the next phase "
+                                          "replays; after: one graph, buckets after the replay); + 1 packed metric all-reduce"
+                                          % (len(reducer.buckets), sum(b["numel"] for b in reducer.buckets), dist.get_backend(), mode),
+                    "step_mode": mode,
                     "same_graphs_step_ms_with_allreduce": 1e3 * with_comm / n_steps,
                     "same_graphs_step_ms_without_allreduce": 1e3 * without / n_steps,
                     "allreduce_exposed_ms_per_step": 1e3 * (with_comm - without) / n_steps})

@@ -45,7 +45,7 @@ def main():
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
         step = engine.GraphedTrainStep(twin, opt_g, batches[0], reducer=reducer, reduce_in_graph=True)
-    fell_back = any("reduced after each replay" in str(w.message) for w in caught)
+    fell_back = any("reduced outside the graphs" in str(w.message) for w in caught)
     losses_g, negs = [], []
     for b in batches:
         losses_g.append(step(b)[0].item())

@@ -75,7 +75,11 @@ def reference_rspmm(dst, src, rel, w, relation, x, n_rows, sum, mul):
         message = message * w.unsqueeze(-1)                                # layer.py:275
     index = dst.unsqueeze(-1).expand_as(message)
     reduce = {"add": "sum", "max": "amax", "min": "amin"}[sum]             # scatter_add / scatter_max / scatter_min
-    out = torch.zeros(n_rows, x.shape[1], device=x.device, dtype=x.dtype)
+    # (the fill value is excluded from the result, include_self=False, but ATen's amin / amax BACKWARD still counts a fill that
+    # happens to equal the result as one more tied element and halves the gradient -- a message of exactly 0.0 did that with a
+    # zero fill; torch_scatter's scatter_min / scatter_max, which the reference calls, have no fill.  Fill with the identity.)
+    fill = {"add": 0.0, "max": float("-inf"), "min": float("inf")}[sum]
+    out = torch.full((n_rows, x.shape[1]), fill, device=x.device, dtype=x.dtype)
     return out.scatter_reduce(0, index, message, reduce=reduce, include_self=False)
 
 
@@ -131,10 +135,30 @@ def test_operator_equals_reference_definition_at_baseline_shapes(name, F, weight
         assert torch.equal(out[rows], want[rows]), "min/max differ from the reference definition"
         fmax = torch.finfo(torch.float32).max
         assert (out[~rows] == (fmax if sum == "min" else -fmax)).all()
-    # gradients: sums over the edges of a source node / of a relation (for min / max over the selected edges only --
-    # distinct random messages, no ties -- which the sums over all edges bound from above)
-    assert ((d_x - want_d_x).abs() <= bound(n_x, s_x, 1e-6)).all()
-    assert ((d_rel - want_d_rel).abs() <= bound(n_rel_terms, s_rel, 1e-5)).all()
+    # gradients: sums over the edges of a source node / of a relation (for min / max over the selected edges only, which the
+    # sums over all edges bound from above).  Exact TIES of a minimum / maximum are a convention, not part of the definition:
+    # torchdrug's rspmm backward feeds every tied edge (mirrored by the kernels), scatter_reduce splits evenly.  Random fp32
+    # messages tie with probability ~2^-24 per pair, i.e. a handful of times among the 4e7 outputs of an F = 1 024 launch:
+    # the gradient entries those few outputs feed are left out (and counted).
+    ok_x, ok_rel = torch.ones_like(x, dtype=torch.bool), torch.ones_like(relation, dtype=torch.bool)
+    if sum != "add":
+        with torch.no_grad():
+            node_input, edge_input = x[src], relation[rel]
+            message = edge_input + node_input if mul == "add" else edge_input * node_input
+            if w is not None:
+                message = message * w.unsqueeze(-1)
+            hit = message == want[dst]
+            del node_input, edge_input, message
+            tied = torch.zeros(n, F, device=dev).index_add_(0, dst, hit.float()) > 1.5
+            tied_edge = hit & tied[dst]
+            n_tied = int(tied.sum())
+            assert n_tied <= 1e-5 * tied.numel() + 2, "%d tied outputs: not the rare accident the mask is meant for" % n_tied
+            if n_tied:
+                ok_x = torch.zeros(n, F, device=dev).index_add_(0, src, tied_edge.float()) < 0.5
+                ok_rel = torch.zeros(n_rel, F, device=dev).index_add_(0, rel, tied_edge.float()) < 0.5
+            del hit, tied_edge
+    assert ((d_x - want_d_x).abs() <= bound(n_x, s_x, 1e-6))[ok_x].all()
+    assert ((d_rel - want_d_rel).abs() <= bound(n_rel_terms, s_rel, 1e-5))[ok_rel].all()
 
 
 def _entity_model(aggregate_func, message_func, n_rel_base, layers=3):
@@ -333,8 +357,15 @@ def test_predict_at_batch_16_equals_the_aten_definition(name):
     pos = pred_true.gather(-1, target.unsqueeze(-1))
     gap = torch.where(mask, (pred_true - pos).abs(), torch.full_like(pred_true, float("inf")))
     gap.scatter_(-1, target.unsqueeze(-1), float("inf"))
-    safe = gap.min(dim=-1).values > 2 * e_hip + 1e-9
-    assert safe.float().mean() > 0.8 and torch.equal(rank_hip[safe], rank_true[safe])
+    # integer ranks: a candidate can change sides of the positive only if its fp64 score lies within the two paths' error of
+    # the positive's -- the ranks may differ by at most the number of such candidates (0 for most queries on trained weights;
+    # seeded random-init weights give tightly clustered scores, so the count is reported rather than assumed small)
+    near = (gap <= 2 * e_hip + 1e-9).sum(dim=-1)
+    assert ((rank_hip - rank_true).abs() <= near).all(), (rank_hip, rank_true, near)
+    safe = near == 0
+    assert torch.equal(rank_hip[safe], rank_true[safe])
+    print("%s: %d of %d ranks have no candidate within the fp32 error of the positive; all of those are equal; max |rank "
+          "difference| elsewhere %d" % (name, int(safe.sum()), safe.numel(), int((rank_hip - rank_true).abs().max())))
 
 
 def test_whole_finetune_step_at_wn18rr_batch_16_equals_the_aten_definition():

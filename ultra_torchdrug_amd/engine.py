@@ -123,7 +123,7 @@ class GraphedPredict:
 
 
 class GraphedTrainStep:
-    """One fine-tuning step (``ultra/engine.py:62-92``) for a fixed batch size as ONE hipGraph: strict negative
+    """One fine-tuning step (``ultra/engine.py:62-92``) for a fixed batch size as hipGraph replays: strict negative
     sampling, removal of the batch's own edges, forward, backward.  A step is ~800 launches, most of them tiny, and
     their host-side issue cost exceeds the GPU time of the kernels.  Nothing in the step has a data-dependent shape any
     more: the negatives come from the sorted completion keys (``ultra_strict_negative``) and the edge removal from a
@@ -132,28 +132,36 @@ class GraphedTrainStep:
     eagerly.  Models the native removal does not cover (min / max / PNA aggregation, ``remove_one_hop``) keep eager
     steps: use :func:`train_step`.
 
-    With a :class:`GradientReducer` the gradient all-reduce goes one of two ways:
+    Without a reducer (one rank): ONE graph.  With a :class:`GradientReducer` the gradient all-reduce goes one of three ways
+    (``mode`` tells which is active):
 
-    * default -- the step is captured with the reducer's hooks paused and the buckets go out right after each replay
-      (``reducer.reduce_all()``: bucket order, side stream), i.e. communication FOLLOWS the replayed backward;
-    * ``reduce_in_graph=True`` -- the hooks stay live during the capture, so every bucket's pack and RCCL all-reduce become
-      nodes of the graph on the reducer's side stream, dependent on that layer's gradients only (the overlap of an eager
-      ``train_step`` with hooks, under replay), and ``finish()`` is captured too.  The captured step is then VERIFIED
-      before it is used: two replays against eager backward passes on the same batch and negatives; any difference
-      drops back to the default with a warning.  On the runtime this was developed on (PyTorch 2.10 + ROCm 7.0, RCCL
-      2.26, one-rank group) the verification fails -- a captured all-reduce alone replays correctly, the captured step
-      with bucket traffic does not (``tools/debug/graph_collective_probe.py``, ``graphed_reducer_diag2.py``; DESIGN.md
-      section 6), and once in a while the verification's replay ends the process with a HIP abort -- so the flag is
-      opt-in, its test runs in a child process, and the overlap under replay remains unproven there.
-    ``reduce_in_graph`` (attribute) tells which form is active.
+    * ``"phased"`` (default) -- the step is captured as THREE graphs that share one memory pool, cut where the gradient
+      buckets become complete: (1) forward + backward through the score head and the later half of the entity layers,
+      (2) the earlier entity layers + the grouped relation projections, (3) the relation model.  Each graph ends by packing
+      its buckets into the reducer's persistent flat buffers (kernel nodes); BETWEEN the replays the buckets of the finished
+      phase are all-reduced eagerly on the reducer's side stream while the next phase's replay runs on the compute stream --
+      the BASELINE north star's "overlapped with the next layer's rspmm on a side HIP stream", with no collective node in any
+      hipGraph (what makes ``reduce_in_graph`` fail on this runtime is not in play).  The parameters' ``.grad`` are views of
+      the flat buffers: RCCL averages in place and nothing is unpacked.  The backward is split with ``torch.autograd.grad``
+      at the tensors ``model.last_cuts`` / ``task.last_relation_inputs`` (same kernels, same accumulation order as the
+      single backward: the captured phases are verified against an eager backward before use; a model the cut does not
+      cover drops to ``"after"`` with a warning).
+    * ``"after"`` -- one graph, hooks paused; the buckets go out after the replay (``reducer.reduce_all()``): communication
+      FOLLOWS the backward (round 3's default).
+    * ``"in_graph"`` (``reduce_in_graph=True``, opt-in) -- the hooks stay live during the capture, so every bucket's pack and
+      RCCL all-reduce become nodes of the graph; verified before use.  On the runtime this was developed on (PyTorch 2.10 +
+      ROCm 7.0, RCCL 2.26, one-rank group) the verification fails -- a captured all-reduce alone replays correctly, the
+      captured step with bucket traffic does not (``tools/debug/graph_collective_probe.py``), and once
+      in a while the verification's replay ends the process with a HIP abort -- so its test runs in a child process.
 
-    Collectives of the CONSTRUCTOR: the warm-up steps and the capture run with the reducer's hooks paused, so they issue none;
-    RCCL is warmed by ``reducer.warm()`` (one explicit all-reduce per bucket) unless ``warm_collectives=False`` (a caller
-    that builds several steps, :class:`GraphedMultiGraphTrainStep`, warms once itself).  Either way every rank that
-    constructs a step issues the same collectives, whatever graph its example batch is from.  Every ``__call__`` then sends
-    exactly ONE round of buckets (checked)."""
+    Collectives of the CONSTRUCTOR: the warm-up steps, the captures and the verification run with the reducer's hooks paused,
+    so they issue none; RCCL is warmed by ``reducer.warm()`` (one explicit all-reduce per bucket) unless
+    ``warm_collectives=False`` (a caller that builds several steps, :class:`GraphedMultiGraphTrainStep`, warms once itself).
+    Every rank that constructs a step issues the same collectives, whatever graph its example batch is from, and every
+    ``__call__`` sends exactly ONE round of buckets (checked)."""
 
-    def __init__(self, task, optimizer, example_batch, warmup=3, reducer=None, reduce_in_graph=False, warm_collectives=True):
+    def __init__(self, task, optimizer, example_batch, warmup=3, reducer=None, reduce_in_graph=False, warm_collectives=True,
+                 phased=True):
         assert example_batch.is_cuda and task.training
         model = task.model
         if model.remove_one_hop or not model._removal_by_zero_weight(sums_only=True):
@@ -162,12 +170,14 @@ class GraphedTrainStep:
         self.task, self.optimizer, self.reducer = task, optimizer, reducer
         self.static_batch = validate_triples(task, example_batch).clone()
         self.reduce_in_graph = False
+        self.mode = "single"
         self.communicate = True                     # False (bench.py): replay + optimizer only, to price the collectives
         model.check_indices = False
         try:
+            import contextlib
+            import warnings
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            import contextlib
             quiet = reducer.paused() if reducer is not None else contextlib.nullcontext()
             with torch.cuda.stream(side), quiet:    # hooks paused: the warm-up issues NO collective (ranks of a multi-graph
                 for _ in range(warmup):             # run build their steps on different graphs)
@@ -175,28 +185,40 @@ class GraphedTrainStep:
                     loss, _ = task(self.static_batch)
                     loss.backward()
             torch.cuda.current_stream().wait_stream(side)
+            active = reducer is not None and reducer._active()
             if reducer is not None and (warm_collectives or reduce_in_graph):
                 reducer.warm()                      # RCCL warm: one all-reduce per bucket, the same on every rank
-            if reducer is not None and reduce_in_graph and reducer.overlap and reducer._active():
-                import warnings
+            if active and reduce_in_graph and reducer.overlap:
                 try:
                     self._capture(reduce=True)
                     self.reduce_in_graph = self._verify_captured_reduction()
                     if not self.reduce_in_graph:
                         warnings.warn("GraphedTrainStep: the step captured WITH the gradient all-reduce does not reproduce "
-                                      "eager gradients on this runtime; the buckets are reduced after each replay instead")
+                                      "eager gradients on this runtime; the buckets are reduced outside the graphs instead")
                 except Exception as err:            # the runtime refused collective nodes
                     warnings.warn("GraphedTrainStep: capturing the gradient all-reduce failed (%s); the buckets are "
-                                  "reduced after each replay instead" % (str(err).splitlines()[0] if str(err) else type(err).__name__))
-                if not self.reduce_in_graph:
+                                  "reduced outside the graphs instead" % (str(err).splitlines()[0] if str(err) else type(err).__name__))
+                if self.reduce_in_graph:
+                    self.mode = "in_graph"
+                else:
                     torch.cuda.synchronize()
                     reducer.abandon()
-            if not self.reduce_in_graph:
+            if active and phased and not self.reduce_in_graph:
+                try:
+                    self._capture_phased()
+                    self.mode = "phased"
+                except _NoPhases as err:
+                    warnings.warn("GraphedTrainStep: %s; the buckets are reduced after the replay instead" % err)
+                    self.graphs = None
+                    torch.cuda.synchronize()
+            if self.mode not in ("in_graph", "phased"):
                 self._capture(reduce=False)
-            self.last_negatives = task.last_negatives       # (B, num_negative): rewritten by every replay
-            # the gradient tensors THIS graph writes (allocated in its pool during the capture): several captured steps
-            # over one set of parameters (GraphedMultiGraphTrainStep) re-bind theirs before the optimizer step
-            self._grads = [(p, p.grad) for p in task.parameters() if p.grad is not None]
+                self.mode = "after" if active else "single"
+                # the gradient tensors THIS graph writes (allocated in its pool during the capture): several captured steps
+                # over one set of parameters (GraphedMultiGraphTrainStep) re-bind theirs before the optimizer step
+                self._grads = [(p, p.grad) for p in task.parameters() if p.grad is not None]
+            elif self.mode == "in_graph":
+                self._grads = [(p, p.grad) for p in task.parameters() if p.grad is not None]
         finally:
             model.check_indices = True
 
@@ -211,6 +233,132 @@ class GraphedTrainStep:
             self.static_loss.backward()
             if reduce:
                 self.reducer.finish()
+        self.last_negatives = self.task.last_negatives      # (B, num_negative): the tensor every replay rewrites
+
+    # ------------------------------------------------------------------ phased capture
+    def _phases(self):
+        """Which phase of the backward completes each parameter's gradient -- 0: score head and the entity layers after the
+        cut; 1: the earlier entity layers, the grouped relation projections and anything else of the entity model; 2: the
+        relation models -- and, from that, the reducer's buckets per phase (contiguous runs in bucket order)."""
+        task, reducer = self.task, self.reducer
+        k = self.cut_after
+        phase_of = {}
+        for name, p in task.named_parameters():
+            parts = name.split(".")
+            if parts[0] == "rel_models":
+                phase = 2
+            elif name.startswith("model.mlp."):
+                phase = 0
+            elif (parts[0] == "model" and parts[1] == "layers" and "relation_projection" not in parts
+                  and parts[3] in ("linear", "layer_norm") and int(parts[2]) >= k):
+                phase = 0
+            else:
+                phase = 1
+            phase_of[id(p)] = phase
+        groups = [[], [], []]
+        last = 0
+        for b, bucket in enumerate(reducer.buckets):
+            phase = max(phase_of[id(p)] for p in bucket["params"])
+            if phase < last:
+                raise _NoPhases("bucket `%s` completes in phase %d after a bucket of phase %d" % (bucket["name"], phase, last))
+            last = phase
+            groups[phase].append(b)
+        return phase_of, groups
+
+    def _capture_phased(self):
+        task, model, reducer = self.task, self.task.model, self.reducer
+        if len(model.layers) < 2 or not task.rel_models:
+            raise _NoPhases("the model has fewer than two entity layers or no relation model")
+        self.cut_after = model.cut_at()
+        phase_of, groups = self._phases()
+        device = self.static_batch.device
+        reducer.flat_buffers(device)
+        bucketed = {id(p) for b in reducer.buckets for p in b["params"]}
+        params = [[p for p in task.parameters() if p.requires_grad and phase_of[id(p)] == phase] for phase in range(3)]
+        self.optimizer.zero_grad(set_to_none=True)
+        graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+        produced = {}
+
+        def keep(ps, grads):
+            for p, g in zip(ps, grads):
+                if g is not None:
+                    if id(p) not in bucketed:
+                        raise _NoPhases("a parameter outside the reducer's buckets receives a gradient")
+                    produced[id(p)] = g
+
+        def pack(phase):
+            for b in groups[phase]:
+                reducer.pack(b, produced)
+
+        with reducer.paused():
+            with torch.cuda.graph(graphs[0], capture_error_mode="relaxed"):
+                self.static_loss, self.static_metric = task(self.static_batch)
+                cuts, rel_inputs = model.last_cuts, task.last_relation_inputs
+                self.last_negatives = task.last_negatives   # (B, num_negative): the tensor every replay rewrites
+                if cuts is not None and rel_inputs:
+                    got = torch.autograd.grad(self.static_loss, params[0] + cuts, allow_unused=True)
+                    keep(params[0], got[:len(params[0])])
+                    cut_grads = got[len(params[0]):]
+                    pack(0)
+            if cuts is None or not rel_inputs or any(g is None for g in cut_grads):
+                raise _NoPhases("this model / batch does not expose the cut tensors (grouped relation tables, sum layers)")
+            with torch.cuda.graph(graphs[1], pool=graphs[0].pool(), capture_error_mode="relaxed"):
+                got = torch.autograd.grad(cuts, params[1] + list(rel_inputs), grad_outputs=list(cut_grads), allow_unused=True)
+                keep(params[1], got[:len(params[1])])
+                rel_grads = got[len(params[1]):]
+                pack(1)
+            live = [(t, g) for t, g in zip(rel_inputs, rel_grads) if g is not None]
+            if not live:
+                raise _NoPhases("no gradient reaches the relation model")
+            with torch.cuda.graph(graphs[2], pool=graphs[0].pool(), capture_error_mode="relaxed"):
+                got = torch.autograd.grad([t for t, _ in live], params[2], grad_outputs=[g for _, g in live], allow_unused=True)
+                keep(params[2], got)
+                pack(2)
+        self.graphs, self.groups = graphs, groups
+        views = reducer.views()
+        self._grads = [(p, views[id(p)]) for p in task.parameters() if id(p) in bucketed]
+        self._local = produced                       # (kept alive: the graphs write these)
+        if not self._verify_phases():
+            raise _NoPhases("the phased backward does not reproduce the gradients of the single backward on this model")
+
+    def _replay_phases(self, communicate):
+        reducer = self.reducer
+        for graph, group in zip(self.graphs, self.groups):
+            graph.replay()
+            if communicate:
+                reducer.launch_group(group)         # side stream: RCCL works while the next phase replays
+        if communicate:
+            reducer.wait_groups()
+
+    def _verify_phases(self):
+        """One replay of the three phases (no collective) against an eager single backward on the same batch and the
+        negatives the replay drew: every gradient packed into the flat buffers must EQUAL the eager one."""
+        task = self.task
+        self._replay_phases(communicate=False)
+        torch.cuda.synchronize()
+        got = {id(p): view.clone() for p, view in self._grads}
+        loss_replayed = self.static_loss.detach().clone()
+        task._static_negative = self.last_negatives.clone()
+        saved = [(p, p.grad) for p in task.parameters()]
+        for p in task.parameters():
+            p.grad = None
+        try:
+            with self.reducer.paused():
+                loss, _ = task(self.static_batch)
+                loss.backward()
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(loss.detach(), loss_replayed))
+            for p in task.parameters():
+                if id(p) in got:
+                    want = p.grad if p.grad is not None else torch.zeros_like(p)
+                    ok = ok and bool(torch.equal(got[id(p)], want))
+                elif p.grad is not None:
+                    ok = False
+        finally:
+            task._static_negative = None
+            for p, g in saved:
+                p.grad = g
+        return ok
 
     def _verify_captured_reduction(self, rounds=2):
         """Replays of the step captured with the bucket traffic against eager backward passes on the same batch and the
@@ -226,7 +374,7 @@ class GraphedTrainStep:
             got = [g.clone() for g in captured]
             for p in params:
                 p.grad = None
-            task._static_negative = task.last_negatives.clone()
+            task._static_negative = self.last_negatives.clone()
             try:
                 with self.reducer.paused():
                     loss, _ = task(self.static_batch)
@@ -251,25 +399,38 @@ class GraphedTrainStep:
         self.static_batch.copy_(batch)
         for p, grad in self._grads:
             p.grad = grad
+        reducer = self.reducer
+        if self.mode == "phased":
+            sent = reducer.total_launched
+            self._replay_phases(self.communicate)
+            if self.communicate and reducer.total_launched - sent != len(reducer.buckets):
+                raise RuntimeError("GraphedTrainStep: %d bucket all-reduces went out in one step, expected %d"
+                                   % (reducer.total_launched - sent, len(reducer.buckets)))
+            self.optimizer.step()
+            return self.static_loss.detach(), (reduce_metrics(self.static_metric) if self.communicate else self.static_metric)
         if not self.communicate:                    # measurement only: the step without any cross-rank traffic
             self.graph.replay()
             self.optimizer.step()
             return self.static_loss.detach(), self.static_metric
-        if self.reducer is not None and not self.reduce_in_graph:
-            sent = self.reducer.total_launched
-            with self.reducer.paused():             # (replays fire no hooks; this keeps it so by construction)
+        if self.mode == "after":
+            sent = reducer.total_launched
+            with reducer.paused():                  # (replays fire no hooks; this keeps it so by construction)
                 self.graph.replay()
-            self.reducer.reduce_all()
-            if self.reducer._active() and self.reducer.total_launched - sent != len(self.reducer.buckets):
+            reducer.reduce_all()
+            if reducer.total_launched - sent != len(reducer.buckets):
                 raise RuntimeError("GraphedTrainStep: %d bucket all-reduces went out in one step, expected %d -- the ranks' "
-                                   "sequences of collectives would diverge" % (self.reducer.total_launched - sent,
-                                                                               len(self.reducer.buckets)))
+                                   "sequences of collectives would diverge" % (reducer.total_launched - sent,
+                                                                               len(reducer.buckets)))
         else:
             self.graph.replay()
-            if self.reducer is None:
+            if reducer is None:
                 allreduce_gradients(self.task)
         self.optimizer.step()
         return self.static_loss.detach(), reduce_metrics(self.static_metric)
+
+
+class _NoPhases(RuntimeError):
+    """The phased capture does not apply to this model (GraphedTrainStep falls back to one graph)."""
 
 
 class GraphedMultiGraphTrainStep:
@@ -290,7 +451,7 @@ class GraphedMultiGraphTrainStep:
     ``examples``: optional ``{graph_id: (batch_size, 3) triples}`` to capture with (default: the first ``batch_size`` fact
     edges of each graph).  Contexts with fewer than ``batch_size`` fact edges keep the eager step."""
 
-    def __init__(self, task, optimizer, batch_size, reducer=None, warmup=3, examples=None):
+    def __init__(self, task, optimizer, batch_size, reducer=None, warmup=3, examples=None, phased=True):
         self.task, self.optimizer, self.batch_size, self.reducer, self.warmup = task, optimizer, int(batch_size), reducer, warmup
         self.steps = {}
         self.communicate = True                     # see GraphedTrainStep.communicate
@@ -305,7 +466,7 @@ class GraphedMultiGraphTrainStep:
                 if len(example) != self.batch_size:
                     continue
                 self.steps[str(name)] = GraphedTrainStep(task, optimizer, example.to(device), warmup=warmup, reducer=reducer,
-                                                         warm_collectives=False)
+                                                         warm_collectives=False, phased=phased)
         finally:
             if saved is not None:
                 task.use(saved)
@@ -537,8 +698,10 @@ class GradientReducer:
     ``ultra/engine.py:55-60``; BASELINE north star: "overlapped with the next layer's rspmm on a side HIP stream").
 
     Buckets follow the order in which backward produces gradients: the score head first, then the entity layers last to
-    first, then the relation-model layers last to first -- one bucket per layer (a layer's parameters become ready
-    together, right after its rspmm backward).  A ``post_accumulate_grad`` hook per parameter counts a bucket down; when
+    first (each layer's ``linear`` + ``layer_norm``: ready right after its rspmm backward), then ONE bucket with the relation
+    projections of all entity layers (a single grouped autograd node that runs after the first layer's backward; round 3 kept
+    them in their layers' buckets, so no entity bucket could leave before the whole entity stack was done), then the
+    relation-model layers last to first.  A ``post_accumulate_grad`` hook per parameter counts a bucket down; when
     the last gradient of a bucket exists the bucket is packed on the compute stream into its PERSISTENT flat buffer
     (allocated once: nothing is allocated or freed per step, so the same code is capturable into a hipGraph), and its
     all-reduce is enqueued on a SIDE stream (RCCL runs it there while the compute stream continues with the next layer's
@@ -559,10 +722,15 @@ class GradientReducer:
 
         def bucket_key(name):
             parts = name.split(".")
+            if "relation_projection" in parts:
+                # the grouped projections of ALL entity layers are one autograd node whose backward runs after the first
+                # entity layer's (model._relation_tables): their gradients become ready together, late -- in a bucket of
+                # their own, or every entity layer's bucket would wait for them and nothing would overlap
+                return (2, 0, parts[0] + ".relation_projections")
             if "layers" in parts and not name.startswith("model.mlp"):
                 i = parts.index("layers")
                 stack = 0 if parts[0] == "model" else 1
-                return (1 + stack, -int(parts[i + 1]), ".".join(parts[:i + 2]))
+                return (1 + 2 * stack, -int(parts[i + 1]), ".".join(parts[:i + 2]))
             return (0, 0, parts[0] + "." + parts[1] if len(parts) > 1 else parts[0])      # score head, query embeddings
 
         groups = {}
@@ -655,9 +823,9 @@ class GradientReducer:
                 self._side = torch.cuda.Stream(device=flat.device)
             self._side.wait_stream(torch.cuda.current_stream(flat.device))   # the pack must be complete
             with torch.cuda.stream(self._side):
-                bucket["work"] = dist.all_reduce(flat, async_op=True)        # RCCL, enqueued behind the side stream
+                bucket["work"] = dist.all_reduce(flat, op=self._op()[0], async_op=True)     # RCCL, enqueued behind the side stream
         else:
-            bucket["work"] = dist.all_reduce(flat, async_op=True)
+            bucket["work"] = dist.all_reduce(flat, op=self._op()[0], async_op=True)
         self._launched += 1
         self.total_launched += 1
 
@@ -686,6 +854,83 @@ class GradientReducer:
             work.wait()
         return len(works)
 
+    # ------------------------------------------------------------------ phased steps (engine.GraphedTrainStep)
+    def _op(self):
+        """Averaging inside the collective where the backend has it (RCCL: no division kernel per bucket); gloo sums."""
+        if self.average and get_world_size() > 1 and dist.get_backend() == "nccl":
+            return dist.ReduceOp.AVG, False
+        return dist.ReduceOp.SUM, self.average and get_world_size() > 1
+
+    def flat_buffers(self, device):
+        """The persistent flat buffer of every bucket (allocated on first use, never per step)."""
+        for bucket in self.buckets:
+            if bucket["flat"] is None or bucket["flat"].device != device:
+                bucket["flat"] = torch.zeros(bucket["numel"], dtype=torch.float32, device=device)
+        return [bucket["flat"] for bucket in self.buckets]
+
+    def views(self):
+        """``{id(param): view of its slice of the bucket's flat buffer}``: a step that packs its gradients into the flat
+        buffers binds these as ``param.grad`` -- the all-reduce then happens in place under the optimizer's feet and nothing
+        is unpacked."""
+        out = {}
+        for bucket in self.buckets:
+            offset = 0
+            for p in bucket["params"]:
+                out[id(p)] = bucket["flat"][offset:offset + p.numel()].view_as(p)
+                offset += p.numel()
+        return out
+
+    def pack(self, b, grads):
+        """Bucket ``b``'s gradients (``{id(param): tensor}``; a parameter without one counts as zeros) into its flat buffer:
+        ONE kernel on the current stream, capturable into a hipGraph (a kernel node; no collective is captured)."""
+        bucket = self.buckets[b]
+        torch.cat([(grads[id(p)] if grads.get(id(p)) is not None else torch.zeros_like(p)).reshape(-1)
+                   for p in bucket["params"]], out=bucket["flat"])
+
+    def launch_group(self, group):
+        """All-reduce the (already packed) buckets ``group`` -- ascending bucket indices, continuing where the previous group
+        ended -- on the side stream, behind everything the compute stream has been given so far; the compute stream goes on
+        (the next phase's replay) while RCCL works.  :meth:`wait_groups` ends the round."""
+        if not self._active():
+            return
+        op, divide = self._op()
+        first = None
+        for b in group:
+            if b != self._next:
+                raise RuntimeError("GradientReducer: bucket %d launched out of order (next is %d): every rank must issue "
+                                   "the buckets in the same order" % (b, self._next))
+            flat = self.buckets[b]["flat"]
+            if flat.is_cuda:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=flat.device)
+                if first is None:
+                    self._side.wait_stream(torch.cuda.current_stream(flat.device))
+                    first = b
+                with torch.cuda.stream(self._side):
+                    self.buckets[b]["work"] = dist.all_reduce(flat, op=op, async_op=True)
+            else:
+                self.buckets[b]["work"] = dist.all_reduce(flat, op=op, async_op=True)
+            self._next += 1
+            self._launched += 1
+            self.total_launched += 1
+
+    def wait_groups(self):
+        """The compute stream waits for every bucket launched by :meth:`launch_group`; the flat buffers then hold the
+        averaged gradients (bound as ``param.grad`` through :meth:`views`).  All buckets must have been launched."""
+        if not self._active():
+            self._reset()
+            return
+        if self._next != len(self.buckets):
+            raise RuntimeError("GradientReducer: %d of %d buckets were launched in this round" % (self._next, len(self.buckets)))
+        op, divide = self._op()
+        for bucket in self.buckets:
+            bucket["work"].wait()                   # the current stream (or the host, gloo) waits for this collective
+            if divide:                              # (gloo only: RCCL averages inside the collective)
+                bucket["flat"].div_(get_world_size())
+            bucket["work"] = None
+        self.rounds += 1
+        self._reset()
+
     # ------------------------------------------------------------------ after backward, before optimizer.step()
     def finish(self):
         """Wait for every bucket (launching those whose hooks did not fire: ``overlap=False``, ``paused()`` or a graph
@@ -701,7 +946,7 @@ class GradientReducer:
         for bucket in self.buckets:
             bucket["work"].wait()                                           # compute stream waits for the collective
             flat = bucket["flat"]
-            if self.average and world > 1:
+            if self._op()[1]:
                 flat /= world
             offset = 0
             for p in bucket["params"]:

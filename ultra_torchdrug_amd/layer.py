@@ -224,7 +224,10 @@ class _RelationalConvBase(nn.Module):
         weighted = message * edge_weight
 
         def scatter(src, reduce):
-            out = torch.zeros(n, *message.shape[1:], device=message.device, dtype=message.dtype)
+            # the fill never enters the result (include_self=False; every node receives its boundary message), but ATen's
+            # amax / amin backward counts a fill that EQUALS the result as one more tied element: fill with the identity
+            fill = {"amax": float("-inf"), "amin": float("inf")}.get(reduce, 0.0)
+            out = torch.full((n,) + tuple(message.shape[1:]), fill, device=message.device, dtype=message.dtype)
             return out.scatter_reduce(0, index, src, reduce=reduce, include_self=False)
 
         if self.aggregate_func == "sum":

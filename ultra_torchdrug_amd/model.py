@@ -16,6 +16,20 @@ from .graph import Graph
 
 class TransferNBFNet(nn.Module):
     check_indices = True    # the reference's per-call consistency asserts (host syncs)
+    # Training in phases (engine.GraphedTrainStep with a gradient reducer): an int k makes `bellmanford` record, in
+    # `last_cuts`, the tensors through which ALL gradient flows from the score head and the layers after the k-th into the
+    # first k layers -- the k-th layer's output, the later layers' relation tables and an alias of the query rows that only
+    # the later layers and the head read -- so that backward can stop there (phase 1: head + layers L..k+1) and resume from
+    # there (phase 2) with the first phase's gradient buckets already on their way.  Arithmetic and bits are unchanged.
+    # "auto" = after the middle layer.  The alias is made in every training forward (a view: no kernel), so that eager steps
+    # and phased captured steps sum the query gradient in the SAME association and stay bit-identical; None switches it off.
+    cut_after = "auto"
+    last_cuts = None
+
+    def cut_at(self):
+        if self.cut_after == "auto":
+            return len(self.layers) // 2
+        return self.cut_after
 
     def __init__(self, input_dim, hidden_dims, num_relation=None, symmetric=False, message_func="distmult",
                  aggregate_func="pna", short_cut=False, layer_norm=False, activation="relu", concat_hidden=False,
@@ -116,13 +130,36 @@ class TransferNBFNet(nn.Module):
         graph.relation_tables = self._relation_tables(bs)
         hiddens, step_graphs = [], []
         layer_input = boundary
+        # (only with the grouped relation tables: a layer that projects its own table sends gradient to the relation
+        # representations past the recorded tensors)
+        tables = graph.relation_tables
+        cut = self.cut_at()
+        cut = cut if (cut and torch.is_grad_enabled() and not separate_grad and 0 < cut < len(self.layers)
+                      and tables is not None and all(id(c) in tables for c in self.layers)
+                      and getattr(graph, "boundary_sparse", None) is not None) else None
+        self.last_cuts = None
+        late_graph, query_late = graph, query
+        if cut is not None:
+            import copy
+            # alias NODES: autograd decides per node what a partial backward must run, so the late readers get nodes of their
+            # own -- the gradient of the late readers alone arrives at them, and stopping there does not drag the grouped
+            # projection node (whose other outputs the early layers feed) or the query's producer into the first phase
+            query_late = query.view_as(query)
+            late_graph = copy.copy(graph)
+            late_graph.query, late_graph.boundary_sparse = query_late, (graph.boundary_sparse[0], query_late)
+            late_graph.relation_tables = dict(tables)
+            for conv in list(self.layers)[cut:]:
+                late_graph.relation_tables[id(conv)] = tables[id(conv)].view_as(tables[id(conv)])
         # training: the caller reads the LAST layer's output at rows (grad_candidates[b, j], b) only -- the epilogue's
         # backward of that layer then works on the tiles of those rows alone (functional.sum_layer)
         last_tiles = None
         if grad_candidates is not None and torch.is_grad_enabled() and not want_feature and not separate_grad:
             last_tiles = backend.get().candidate_tiles(grad_candidates, bs, graph.num_node)
         for position, conv in enumerate(self.layers):
-            step_graph = graph
+            step_graph = graph if (cut is None or position < cut) else late_graph
+            if cut is not None and position == cut:
+                self.last_cuts = ([layer_input] + [late_graph.relation_tables[id(c)] for c in list(self.layers)[cut:]]
+                                  + [query_late])
             if separate_grad:
                 step_graph = graph.clone()
                 step_graph.query, step_graph.boundary = query, boundary
@@ -137,8 +174,8 @@ class TransferNBFNet(nn.Module):
             layer_input = hidden
 
         if not want_feature:
-            return {"hidden": hiddens[-1], "query": query, "step_graphs": step_graphs}
-        node_query = query.expand(graph.num_node, -1, -1)
+            return {"hidden": hiddens[-1], "query": query_late, "step_graphs": step_graphs}
+        node_query = query_late.expand(graph.num_node, -1, -1)
         if self.concat_hidden:
             output = torch.cat(hiddens + [node_query], dim=-1)
         else:
@@ -215,6 +252,8 @@ class TransferNBFNet(nn.Module):
         if stack is None:
             return None
         und = self._undirected(graph)
+        if und.requires_grad or graph.requires_grad:             # layer.py:299: such a graph takes message + aggregate
+            return None
         csr = und.relcsr
         n_query = 2 * batch.shape[0]
         if not ops.frontier_supported("add", "mul", 64 * n_query):

@@ -128,13 +128,15 @@ class CustomNBFNetFull(CustomNBFNet):
         F = torch.nn.functional
         ops = layer.backend.get()
         if (not getattr(ops, "FAST_INFERENCE", False) or torch.is_grad_enabled() or self.learn_query or self.concat_hidden
-                or not layer.FRONTIER_FIRST_LAYER or not ops.accepts(h_index) or not self.layers):
+                or not layer.FRONTIER_FIRST_LAYER or not ops.accepts(h_index) or not self.layers
+                or graph.requires_grad):                   # layer.py:299: such a graph takes message + aggregate
             return None
         for conv in self.layers:
             ok = (isinstance(conv, layer.GeneralizedRelationalConvNBF) and not conv.dependent and conv.message_func == "distmult"
                   and conv.aggregate_func == "sum" and conv.input_dim == 64 and conv.output_dim == 64
                   and tuple(conv.linear.weight.shape) == (64, 128) and conv.linear.bias is not None
                   and (conv.activation is F.relu or not conv.activation) and conv.relation.weight.is_cuda
+                  and conv.relation.weight.dtype == torch.float32 and conv.linear.weight.dtype == torch.float32
                   and (conv.layer_norm is None or (conv.layer_norm.elementwise_affine and conv.layer_norm.bias is not None)))
             if not ok:
                 return None
