@@ -852,6 +852,14 @@ def main():
         finally:
             UL.FRONTIER_FIRST_LAYER = True
         frontier_ms, _ = timed_kernel(lib, events, lambda: UF.rspmm_frontier(und.relcsr, rk, bk), 10)
+        # the same step with the first layer's epilogue over ALL rows (round 3's form; round 4 runs it on the rows the frontier
+        # reaches and broadcasts one constant row everywhere else: ultra_first_layer_sparse_f32)
+        UF.SPARSE_FIRST_LAYER = False
+        try:
+            dense_first = None if args.eager else capture()
+            dense_first_ms = wall_ms(lambda i: step(i, dense_first), n_side, warm=5)
+        finally:
+            UF.SPARSE_FIRST_LAYER = True
         # the same step with the relation representations of all R relations computed once per evaluation run
         # (task.cache_relation_representations, what engine.evaluate does): identical scores, the relation stack leaves
         # the per-batch path.
@@ -1053,6 +1061,7 @@ def main():
                 "ms_per_step_without_first_layer_frontier": no_frontier_ms,
                 "value_all_layers_full_kernel": 12 * E * B * world / (no_frontier_ms * 1e-3),
                 "first_layer_frontier_kernel_ms": frontier_ms,
+                "ms_per_step_with_dense_first_layer_epilogue": dense_first_ms,
                 "ms_per_step_with_cached_relation_representations": cached_ms,
                 "value_with_cached_relation_representations":
                     (visited / (args.steps * world)) / (cached_ms * 1e-3) if cached_ms else None,

@@ -81,6 +81,78 @@ def test_frontier_equals_full_kernel_on_dense_boundary(oracle, case):
         assert np.array_equal(got.cpu().numpy(), want_o + dense.cpu().numpy())
 
 
+@pytest.mark.parametrize("case", ["uniform", "hub_split_rows_multi_relation", "weights", "kg_shape_32_queries", "self_loops"])
+@pytest.mark.parametrize("norm,relu,shortcut", [(True, True, True), (False, True, False), (True, False, True)])
+def test_sparse_first_layer_equals_frontier_plus_dense_epilogue(case, norm, relu, shortcut):
+    """``ultra_first_layer_sparse_f32`` (round 4): the whole first layer with the epilogue on the rows the frontier reaches
+    only, one constant vector broadcast everywhere else, must EQUAL ``ultra_rspmm_frontier_f32`` followed by the dense
+    boundary-form epilogue bit for bit: isolated heads, repeated heads, self loops (the head's own row is then listed by a
+    run, not by its spare slot), hubs with split rows, per-edge weights, and an FB15k237-shaped batch of 32 queries."""
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    dev = _dev()
+    rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)
+    opts = {}
+    if case == "uniform":
+        n, r = 500, 9
+        g = random_graph(seed=1, n_node=n, n_edge=6000, n_rel=r)
+    elif case == "hub_split_rows_multi_relation":
+        n, r = 300, 24
+        g = random_graph(seed=2, n_node=n, n_edge=5000, n_rel=r, hub_row=3, hub_edges=2000)
+        for s_ in (7, 8, 9):
+            g["dst"] = np.concatenate([g["dst"], np.full(r, 3)])
+            g["src"] = np.concatenate([g["src"], np.full(r, s_)])
+            g["rel"] = np.concatenate([g["rel"], np.arange(r, dtype=np.int64)])
+        opts = dict(chunk_edges=16, piece_len=64)
+    elif case == "weights":
+        n, r = 400, 7
+        g = random_graph(seed=3, n_node=n, n_edge=9000, n_rel=r, weights=True, skew=True)
+    elif case == "self_loops":
+        n, r = 200, 5
+        g = random_graph(seed=6, n_node=n, n_edge=3000, n_rel=r, skew=True)
+        loops = np.array([0, 5, 5, 17, 199], dtype=np.int64)                   # node 5 loops through two relations
+        g["dst"] = np.concatenate([g["dst"], loops])
+        g["src"] = np.concatenate([g["src"], loops])
+        g["rel"] = np.concatenate([g["rel"], np.array([1, 0, 3, 2, 4], dtype=np.int64)])
+    else:
+        from graphs import kg_graph
+        n, r = 14541, 474
+        g = kg_graph(1024, n, 272115, 237)
+    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), None if g["w"] is None else _t(g["w"]), n, n, r, **opts)
+    deg_out = torch.bincount(csr.src, minlength=n)
+    if case == "kg_shape_32_queries":
+        order = torch.argsort(deg_out, descending=True)
+        nodes = order[:12].tolist() + order[2000:2016].tolist() + [int(order[0]), int(order[-1]), 0, n - 1]   # hubs, mid, repeat, leaf
+    elif case == "self_loops":
+        nodes = [0, 5, 17, 199, 5, 3, 1, 2]
+    elif case == "hub_split_rows_multi_relation":
+        nodes = [7, 8, 9, 3, 7, 250]
+    else:
+        nodes = [int(deg_out.argmax()), int((deg_out == 0).nonzero()[0]) if (deg_out == 0).any() else 1, 0, n - 1, 5, 5]
+    Q = len(nodes)
+    F = Q * 64
+    relation = torch.from_numpy(rng.standard_normal((r, F)).astype(np.float32)).to(dev)
+    value = torch.from_numpy(rng.standard_normal((Q, 64)).astype(np.float32)).to(dev)
+    node = torch.tensor(nodes, dtype=torch.int32, device=dev)
+    lin = torch.nn.Linear(128, 64).to(dev)
+    ln = torch.nn.LayerNorm(64).to(dev) if norm else None
+    with torch.no_grad():
+        if ln is not None:
+            ln.weight.copy_(torch.from_numpy(rng.standard_normal(64).astype(np.float32)))
+            ln.bias.copy_(torch.from_numpy(rng.standard_normal(64).astype(np.float32)))
+        args = (lin.weight, lin.bias, ln.weight if ln else None, ln.bias if ln else None, 1e-5, relu, shortcut)
+        update = UF.rspmm_frontier(csr, relation, (node, value)).view(n, Q, 64)
+        touched = int((update != 0).any(-1).sum())
+        want = UF.combine_forward(None, update, *args, reuse_update=False, input_boundary=(node, value))
+        got = UF.first_layer_forward(csr, relation, (node, value), *args)
+        assert got is not None, "the sparse first layer declined a shape it should take"
+        assert got.shape == want.shape and torch.equal(got, want), "max |diff| %.3g" % (got - want).abs().max()
+        again = UF.first_layer_forward(csr, relation, (node, value), *args)          # the row list is rebuilt every launch
+        assert torch.equal(again, want)
+    run_prefix, max_runs = csr.frontier_runs
+    assert run_prefix.dtype == torch.int32 and run_prefix.shape == (csr.n_edges,) and int(run_prefix[-1]) >= max_runs > 0
+    assert touched < n * Q                                                            # (some rows really are the constant)
+
+
 def test_first_layer_uses_the_frontier_and_predict_is_unchanged():
     """task.predict with and without the first-layer shortcut: identical scores (the shortcut is bit-compatible)."""
     from ultra_torchdrug_amd import layer

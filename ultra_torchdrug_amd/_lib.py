@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ULTRA_RSPMM_LIB: load another build of the same ABI (kernel A/B runs, tools/kbench.py)
 LIB_PATH = os.environ.get("ULTRA_RSPMM_LIB") or os.path.join(_HERE, "libultra_rspmm.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SUM_OPS = {"add": 0, "min": 1, "max": 2}
 MUL_OPS = {"mul": 0, "add": 1}
@@ -54,6 +54,8 @@ EXPORTS = (
     "ultra_rspmm_fwd_f32",
     "ultra_rspmm_forward_boundary_f32",
     "ultra_rspmm_frontier_f32",
+    "ultra_first_layer_sparse_supported",
+    "ultra_first_layer_sparse_f32",
     "ultra_rspmm_backward_boundary_rows_f32",
     "ultra_rspmm_backward_boundary_rows_workspace",
     "ultra_rspmm_backward_f32",
@@ -148,6 +150,11 @@ def load():
     lib.ultra_rspmm_backward_boundary_rows_workspace.argtypes = [i64]
     lib.ultra_rspmm_frontier_f32.restype = i32
     lib.ultra_rspmm_frontier_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp]
+    lib.ultra_first_layer_sparse_supported.restype = i32
+    lib.ultra_first_layer_sparse_supported.argtypes = [i64, i64, i64]
+    lib.ultra_first_layer_sparse_f32.restype = i32
+    lib.ultra_first_layer_sparse_f32.argtypes = [seg, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp, vp,
+                                                 i64, i64, vp]
     lib.ultra_rspmm_backward_f32.restype = i32
     lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_accumulate_f32.restype = i32

@@ -5,7 +5,8 @@ The product has exactly ONE backend: :mod:`ultra_torchdrug_amd.functional`, i.e.
 optional functions: a backend is an object with this complete interface
 
     accepts(tensor) -> bool            tensors this backend computes on (HIP library: ``tensor.is_cuda``)
-    generalized_rspmm, rspmm_forward, rspmm_sum_plus, rspmm_frontier, frontier_supported, sum_layer, remove_triples
+    generalized_rspmm, rspmm_forward, rspmm_sum_plus, rspmm_frontier, frontier_supported, first_layer_forward, sum_layer,
+    remove_triples
     combine, linear_supported, linear_forward, relation_project, relation_project_train, score_all_entities
     filtered_rank, filtered_rank_keys, strict_negatives, statistics, bce_adversarial_loss, candidate_tiles,
     score_candidates_supported, score_candidates

@@ -664,6 +664,7 @@ constexpr int kCbStride = 132;                 // 128 floats + 4 pad
 constexpr int kCbWaves = 4;                    // waves per workgroup
 constexpr int kCbTileFloats = kCbRows * kCbStride;
 constexpr int kCbLdsQueries = 128;             // boundary form: up to this many queries keep node + value in LDS
+static_assert(kCbLdsQueries == kSparseMaxQueries, "const_fill_kernel lays out one slot range per LDS-resident query");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -686,6 +687,10 @@ struct CombineParams {
     const int32_t *in_bnode;     // [rpn]
     const float *in_bvec;        // [rpn, 64]
     int rpn;                     // rows per node = number of queries
+    // BND = 3 (sparse first layer): the tiles are made of the rows LISTED in row_list[0 .. *list_count) (row id = node * rpn +
+    // query, -1 = empty slot), read from and written back to `update` / `out` at those rows; `rows` bounds the row ids
+    const int32_t *row_list;
+    const int32_t *list_count;
 };
 
 // PF = true (large inputs): one wave per SIMD (up to 512 VGPRs); the NEXT tile's 16 KiB are fetched into registers
@@ -698,6 +703,10 @@ struct CombineParams {
 // in flight at its join (vmcnt is in order) -- 129 vs 94 us -- and cost the common form registers (100 -> 145 us).
 // ZOUT: the training forward also writes z = Linear(cat[input, update]) (the LayerNorm's input) so that the fused backward
 // loads it instead of recomputing it -- a third of that kernel's matrix work.
+// BND = 3: the first layer on the rows the frontier kernel touched only (a row list instead of consecutive rows; boundary
+// tables in LDS as in BND = 1).  BND = 4: one tile whose input and update rows are all zero -- what the epilogue makes of
+// a row the frontier did not touch; its first row is the constant the rest of the layer's output is filled with.  Both
+// run the same arithmetic on a row as every other form: a row's result does not depend on its tile mates.
 template <bool PF, int BND = 0, bool ZOUT = false>
 __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(const CombineParams p) {
     extern __shared__ __attribute__((aligned(16))) float cb_lds[];
@@ -705,7 +714,9 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
     const int wl = uniform(threadIdx.x >> 6);
     float *tile = cb_lds + wl * kCbTileFloats;
     const int i = lane & 31, h = lane >> 5;
-    const long long n_tiles = (p.rows + kCbRows - 1) / kCbRows;
+    int n_list = 0;
+    if constexpr (BND == 3) n_list = uniform(p.list_count[0]);
+    const long long n_tiles = BND == 3 ? ((long long)n_list + kCbRows - 1) / kCbRows : (p.rows + kCbRows - 1) / kCbRows;
     const long long wave_global = (long long)blockIdx.x * kCbWaves + wl;
     const long long wave_total = (long long)gridDim.x * kCbWaves;
 
@@ -728,7 +739,7 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
     // front of the row loads in the in-order vmcnt queue and made the prefetch synchronous: 140 vs 101 us)
     float *bv_lds = gb + 128;                                       // [rpn][64] the queries' boundary values
     int *bn_lds = reinterpret_cast<int *>(bv_lds + (size_t)p.rpn * 64);   // [rpn] their nodes
-    if constexpr (BND == 1) {
+    if constexpr (BND == 1 || BND == 3) {
         for (int j = threadIdx.x; j < p.rpn; j += kCbWaves * 64) bn_lds[j] = p.in_bnode[j];
         for (int j = threadIdx.x; j < p.rpn * 16; j += kCbWaves * 64)
             reinterpret_cast<f32x4 *>(bv_lds)[j] = reinterpret_cast<const f32x4 *>(p.in_bvec)[j];
@@ -737,7 +748,31 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
 
     const long long last = p.rows - 1;
     f32x4 pa[8], pb[8];     // PF: the staged rows of the tile about to be processed
+    int rid[8];             // BND = 3: the listed row of every staged row (-1: none)
     auto fetch = [&](long long t) {
+        if constexpr (BND == 4) {                 // a tile of zeros
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { pa[q] = zero; pb[q] = zero; }
+            return;
+        }
+        if constexpr (BND == 3) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
+                const long long slot = t * kCbRows + r;
+                int row = slot < n_list ? p.row_list[slot] : -1;
+                if ((long long)row >= p.rows) row = -1;                        // (never: a guard for the addresses below)
+                rid[q] = row;
+                const unsigned gr = row >= 0 ? (unsigned)row : 0u;
+                const unsigned node = gr / (unsigned)p.rpn, query = gr - node * (unsigned)p.rpn;
+                const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(bv_lds + query * 64 + c);
+                pa[q] = ((int)node == bn_lds[query]) ? v : zero;
+                pb[q] = *reinterpret_cast<const f32x4 *>(p.update + (long long)gr * 64 + c);
+            }
+            return;
+        }
         // boundary form: (node, query) of the tile's first row once per tile, on the scalar unit (t is wave-uniform); a
         // 64-bit division per fetched row cost 37 us of this kernel's 140 on the headline batch
         long long node0 = 0;
@@ -875,6 +910,19 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
         // UNCONDITIONALLY.  Behind `if (row < rows)` branches the compiler cannot know how many stores are in flight at
         // the top of the loop (stores count in vmcnt on gfx9) and waited with vmcnt(0) for the prefetched rows -- i.e. for
         // the write acknowledgements of the tile just stored, every iteration.
+        if constexpr (BND == 3) {
+            // every row back to where it came from; empty slots store past the descriptor (rows * 256 B < 4 GiB: host check)
+            const __amdgpu_buffer_rsrc_t rsrc_all = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(uint32_t)(p.rows * 256), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
+                const f32x4 d = *reinterpret_cast<const f32x4 *>(tile + r * kCbStride + 64 + c);
+                const uint32_t off = rid[q] >= 0 ? (uint32_t)rid[q] * 256u + (uint32_t)c * 4u : 0xffffffffu;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(qu4, d), rsrc_all, off, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
         const long long left = p.rows - row0;
         const __amdgpu_buffer_rsrc_t rsrc_tile = __builtin_amdgcn_make_buffer_rsrc(
             p.out + row0 * 64, 0, (int)(left < kCbRows ? left : kCbRows) * 256, 0x00020000);
@@ -1367,8 +1415,10 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
                        blocks_per_label / (conc * 2) >= 4)
                     conc *= 2;
                 if (const char *force = getenv("ULTRA_CONC")) {      // experiments: force the number of concurrent tiles
-                    const int want = atoi(force);
-                    if (want >= 1 && blocks_per_label % want == 0) conc = want;
+                    const int want = atoi(force);                    // (ULTRA_CONC_MIN_ROWS: only for gathered matrices of at
+                    const char *min_rows = getenv("ULTRA_CONC_MIN_ROWS");    // least that many rows, i.e. not the relation graphs)
+                    if (want >= 1 && blocks_per_label % want == 0 && (min_rows == nullptr || gather_rows >= atoll(min_rows)))
+                        conc = want;
                 }
                 q.concurrent = conc;
                 rc = launch_quad<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var == 1, grid, kLdsHeader + lds_bytes, stream);
@@ -1583,7 +1633,7 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
         hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<qf4 *>(out), n4);
         HIP_TRY(hipGetLastError());
     }
-    FrontierParams p;
+    FrontierParams p{};
     p.src_ptr = src_ptr;
     p.dst = by_src->node_a;
     p.rel = by_src->rel;
@@ -1618,6 +1668,78 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
         HIP_TRY(hipGetLastError());
     }
     if (ev_stop != nullptr) HIP_TRY(hipEventRecord(ev_stop, s));
+    return ULTRA_OK;
+}
+
+// Sparse first layer of a Bellman-Ford in inference (see include/ultra_rspmm.h): constant tile -> broadcast fill + slot layout
+// -> frontier kernel (rows + their list) -> epilogue over the listed rows.  Four launches, all kernels (capturable).
+int ultra_first_layer_sparse_supported(int64_t n_dst, int64_t n_rel, int64_t n_query) {
+    return n_query > 0 && n_query <= kCbLdsQueries && n_rel > 0 &&
+           (size_t)n_rel * kTile * sizeof(float) <= (size_t)kMaxLdsBytes && n_dst > 0 &&
+           n_dst * n_query * 256 < (1LL << 32) - 65536 && n_dst * n_query < 0x7fffffffLL && !g_force_general;
+}
+
+int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *src_ptr, const int32_t *fwd_rank,
+                                 const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
+                                 const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                                 const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                                 float *out, int32_t *row_list, int32_t *list_offset, float *const_tile, int64_t n_dst,
+                                 int64_t n_rel, void *stream) {
+    int rc = check_segments(by_src);
+    if (rc) return rc;
+    if (!ultra_first_layer_sparse_supported(n_dst, n_rel, n_query) || by_src->piece_len <= 0) return ULTRA_ERR_BAD_SHAPE;
+    if (src_ptr == nullptr || fwd_rank == nullptr || run_prefix == nullptr || relation == nullptr || boundary_node == nullptr ||
+        boundary_value == nullptr || weight == nullptr || bias == nullptr || out == nullptr || row_list == nullptr ||
+        list_offset == nullptr || const_tile == nullptr)
+        return ULTRA_ERR_NULL_POINTER;
+    if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
+    const long long F = n_query * 64;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(relation) | reinterpret_cast<uintptr_t>(boundary_value) |
+         reinterpret_cast<uintptr_t>(const_tile)) & 15u) return ULTRA_ERR_BAD_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo *di = nullptr;
+    rc = device_info(dev, &di);
+    if (rc) return rc;
+    // (1) what the epilogue makes of an untouched row: one tile of zeros through the epilogue kernel itself
+    CombineParams cp{};
+    cp.update = const_tile; cp.weight = weight; cp.bias = bias; cp.gamma = ln_weight; cp.beta = ln_bias;
+    cp.out = const_tile; cp.rows = kCbRows; cp.eps = ln_eps; cp.relu = relu; cp.shortcut = shortcut;
+    cp.in_bnode = boundary_node; cp.in_bvec = boundary_value; cp.rpn = (int)n_query;
+    const size_t lds_cb = (size_t)(kCbWaves * kCbTileFloats + 128 + n_query * 65) * sizeof(float);
+    rc = ensure_lds_attribute(reinterpret_cast<const void *>(combine_kernel<false, 4>), lds_cb);
+    if (rc) return rc;
+    rc = ensure_lds_attribute(reinterpret_cast<const void *>(combine_kernel<false, 3>), lds_cb);
+    if (rc) return rc;
+    hipLaunchKernelGGL((combine_kernel<false, 4>), dim3(1), dim3(kCbWaves * 64), lds_cb, s, cp);
+    HIP_TRY(hipGetLastError());
+    // (2) the constant everywhere + the slot ranges of the row list
+    {
+        const long long n4 = (long long)n_dst * F / 4;
+        const unsigned blocks = (unsigned)((n4 + 256 * 8 - 1) / (256 * 8) < 4096 ? (n4 + 256 * 8 - 1) / (256 * 8) : 4096);
+        hipLaunchKernelGGL(const_fill_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<qf4 *>(out), n4,
+                           reinterpret_cast<const qf4 *>(const_tile), src_ptr, run_prefix, boundary_node, (int)n_query, list_offset);
+        HIP_TRY(hipGetLastError());
+    }
+    // (3) the frontier's rows over it, listed
+    FrontierParams p{};
+    p.src_ptr = src_ptr; p.dst = by_src->node_a; p.rel = by_src->rel; p.weight = by_src->weight; p.fwd_rank = fwd_rank;
+    p.relation = relation; p.bnode = boundary_node; p.bvec = boundary_value; p.out = out; p.F = F;
+    p.piece_len = (int)by_src->piece_len; p.n_rel = (int)n_rel; p.piece_shift = -1;
+    for (int sh = 0; sh < 31; ++sh)
+        if ((1LL << sh) == by_src->piece_len) p.piece_shift = sh;
+    p.run_prefix = run_prefix; p.row_list = row_list; p.list_offset = list_offset;
+    p.slices = kFrontierLdsSlices;
+    const size_t msg_bytes = (size_t)n_rel * kTile * sizeof(float);
+    const int fgrid = (int)n_query * p.slices;
+    rc = by_src->weight == nullptr ? launch_with_lds(frontier_lds_kernel<true>, p, fgrid, msg_bytes, s, kFrontierLdsThreads)
+                                   : launch_with_lds(frontier_lds_kernel<false>, p, fgrid, msg_bytes, s, kFrontierLdsThreads);
+    if (rc) return rc;
+    // (4) the epilogue on the listed rows, in place
+    cp.update = out; cp.out = out; cp.rows = n_dst * n_query; cp.row_list = row_list; cp.list_count = list_offset + n_query;
+    hipLaunchKernelGGL((combine_kernel<false, 3>), dim3((unsigned)(2 * di->n_cu)), dim3(kCbWaves * 64), lds_cb, s, cp);
+    HIP_TRY(hipGetLastError());
     return ULTRA_OK;
 }
 

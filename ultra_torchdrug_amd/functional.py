@@ -21,7 +21,7 @@ import torch
 from . import _lib, _torch_ext
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "candidate_tiles", "score_candidates", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "first_layer_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "candidate_tiles", "score_candidates", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -208,6 +208,52 @@ def rspmm_frontier(csr, relation, boundary):
         _lib.check(lib.ultra_rspmm_frontier_f32(
             csr.by_src.pointer, src_ptr.data_ptr(), fwd_rank.data_ptr(), relation.data_ptr(), b_node.data_ptr(),
             b_value.data_ptr(), 64, out.data_ptr(), n_dst, n_rel, F, _stream()))
+    return out
+
+
+# Sparse first layer in inference (ultra_first_layer_sparse_f32).  ULTRA_SPARSE_FIRST_LAYER=0: frontier kernel + dense epilogue.
+SPARSE_FIRST_LAYER = __import__("os").environ.get("ULTRA_SPARSE_FIRST_LAYER", "1") != "0"
+
+
+def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True,
+                        shortcut=False):
+    """The whole FIRST Bellman-Ford layer in inference -- ``rspmm_frontier`` followed by ``combine_forward(None, update, ...,
+    input_boundary=boundary)``, bit for bit -- with the epilogue on the rows the frontier reaches only: every other row of the
+    layer's output is one constant vector (``relu(LN(bias))``; ``ultra/model.py:116-127``), computed once and broadcast.
+    ``boundary = (node int32 (Q,), value fp32 (Q, 64))``; returns ``(N, Q, 64)``, or ``None`` where the fused entry does not
+    apply (vocabulary beyond LDS, more than 128 queries, outputs beyond 4 GiB: the caller runs the two calls)."""
+    if not SPARSE_FIRST_LAYER:
+        return None
+    b_node, b_value = boundary
+    n_dst, n_src, n_rel = csr.shape
+    n_query = b_node.shape[0]
+    lib = _lib.load()
+    if n_dst != n_src or not lib.ultra_first_layer_sparse_supported(n_dst, n_rel, n_query):
+        return None
+    F = n_query * 64
+    b_value = b_value.contiguous()
+    tensors = [relation, b_value, weight, bias] + ([ln_weight, ln_bias] if ln_weight is not None else [])
+    if (relation.dim() != 2 or tuple(relation.shape) != (n_rel, F) or tuple(b_value.shape) != (n_query, 64) or b_node.dtype != torch.int32
+            or not b_node.is_contiguous() or tuple(weight.shape) != (64, 128)
+            or any(t.dtype != torch.float32 or not t.is_cuda or t.device != relation.device for t in tensors)
+            or b_node.device != relation.device or csr.device != relation.device):
+        raise RuntimeError("first_layer_forward: relation fp32 (%d, %d), boundary (int32 (Q,), fp32 (Q, 64)), a (64, 128) weight, "
+                           "all on one HIP device" % (n_rel, F))
+    relation = relation.contiguous()
+    dev = relation.device
+    src_ptr, fwd_rank = csr.frontier_index
+    run_prefix, max_runs = csr.frontier_runs
+    out = torch.empty(n_dst, n_query, 64, dtype=torch.float32, device=dev)
+    row_list = torch.empty(n_query * (max_runs + 1), dtype=torch.int32, device=dev)
+    list_offset = torch.empty(n_query + 1, dtype=torch.int32, device=dev)
+    const_tile = torch.empty(32 * 64, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.ultra_first_layer_sparse_f32(
+            csr.by_src.pointer, src_ptr.data_ptr(), fwd_rank.data_ptr(), run_prefix.data_ptr(), relation.data_ptr(),
+            b_node.data_ptr(), b_value.data_ptr(), n_query, weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+            ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
+            ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
+            out.data_ptr(), row_list.data_ptr(), list_offset.data_ptr(), const_tile.data_ptr(), n_dst, n_rel, _stream()))
     return out
 
 

@@ -268,9 +268,13 @@ class TransferNBFNet(nn.Module):
         for i, entry in enumerate(stack):
             w, b, g, beta, eps, relu = entry["combine"]
             if i == 0:
-                update = ops.rspmm_frontier(csr, tables[0], boundary).view(n_node, n_query, 64)
-                hidden = ops.combine_forward(None, update, w, b, g, beta, eps, relu, self.short_cut, reuse_update=True,
-                                             input_boundary=boundary)
+                # the whole first layer from the sparse boundary: epilogue on the rows the frontier reaches, one constant
+                # vector everywhere else (same bits as the two calls below, which remain for shapes it does not take)
+                hidden = ops.first_layer_forward(csr, tables[0], boundary, w, b, g, beta, eps, relu, self.short_cut)
+                if hidden is None:
+                    update = ops.rspmm_frontier(csr, tables[0], boundary).view(n_node, n_query, 64)
+                    hidden = ops.combine_forward(None, update, w, b, g, beta, eps, relu, self.short_cut, reuse_update=True,
+                                                 input_boundary=boundary)
             else:
                 update = ops.rspmm_forward(csr, tables[i], hidden.flatten(1), "add", "mul", boundary=boundary)
                 hidden = ops.combine_forward(hidden, update.view(n_node, n_query, 64), w, b, g, beta, eps, relu, self.short_cut,

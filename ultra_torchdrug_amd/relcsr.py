@@ -486,6 +486,27 @@ class RelCSR:
                                     rank_fwd[self._by_src_order].to(torch.int32).contiguous())
         return self._frontier_index
 
+    @property
+    def frontier_runs(self):
+        """``(run_prefix, max_runs)`` for :func:`functional.first_layer_forward`: for every edge of the ``by_src`` order
+        (sorted by (src, dst, rel)) the number of (source, destination) runs that start at or before it -- int32 ``(E,)`` -- and
+        the largest number of distinct destinations any source node has.  Built once per graph; a reweighted RelCSR shares
+        its base's."""
+        base = getattr(self, "_base", None)
+        if base is not None:
+            return base.frontier_runs
+        if getattr(self, "_frontier_runs", None) is None:
+            _ = self.by_src
+            order = self._by_src_order
+            src, dst = self.src[order], self.dst[order]
+            start = torch.ones(self.n_edges, dtype=torch.bool, device=self.device)
+            if self.n_edges > 1:
+                start[1:] = (src[1:] != src[:-1]) | (dst[1:] != dst[:-1])
+            prefix = torch.cumsum(start.to(torch.int32), 0, dtype=torch.int32)
+            runs = torch.bincount(src[start], minlength=self.shape[1]) if self.n_edges else torch.zeros(1, dtype=torch.long)
+            self._frontier_runs = (prefix.contiguous(), int(runs.max()) if runs.numel() else 0)
+        return self._frontier_runs
+
     def with_edge_weights(self, edge_weight):
         """RelCSR over the same edge set with other weights, given per ORIGINAL (un-coalesced) edge; duplicates of
         one triple add up, as ``coalesce()`` would.  Shares the sorted index arrays and chunk schedules."""
