@@ -169,6 +169,14 @@ def test_first_layer_uses_the_frontier_and_predict_is_unchanged():
     real = layer.backend.get().rspmm_frontier
     from ultra_torchdrug_amd import functional as UF
     UF.rspmm_frontier = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    real_first = UF.first_layer_forward                  # the entity stack's first layer: frontier + sparse epilogue, fused
+
+    def counted_first(*a, **k):
+        out = real_first(*a, **k)
+        if out is not None:
+            calls.append(1)
+        return out
+    UF.first_layer_forward = counted_first
     try:
         with torch.no_grad():
             with_frontier = task.predict(batch)
@@ -178,6 +186,7 @@ def test_first_layer_uses_the_frontier_and_predict_is_unchanged():
     finally:
         layer.FRONTIER_FIRST_LAYER = True
         UF.rspmm_frontier = real
+        UF.first_layer_forward = real_first
     assert n_calls == 2 and len(calls) == 2            # entity stack + relation stack, first layer each
     assert torch.equal(with_frontier, without)
 
