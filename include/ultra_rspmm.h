@@ -176,15 +176,15 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
  * = GeneralizedRelationalConv*.forward on `input = boundary` (/root/reference/ultra/model.py:116-127, ultra/layer.py:298-392)
  * -- ultra_rspmm_frontier_f32 followed by ultra_combine_forward_boundary_f32, bit for bit.  A row (v, q) that no out-edge of
  * boundary_node[q] reaches (and v != boundary_node[q]) has a zero input row and a zero update row, so its output is ONE vector
- * for the whole layer, relu(LayerNorm(bias)): the epilogue kernel computes it once on a tile of zeros, a fill kernel
- * broadcasts it, the frontier kernel writes its rows over it AND lists them, and the epilogue runs on the listed rows only
+ * for the whole layer, relu(LayerNorm(bias)): a fill kernel derives it in the epilogue kernel's own order and broadcasts
+ * it, the frontier kernel writes its rows over it AND lists them, and the epilogue runs on the listed rows only
  * (~a fifth of the rows on hub-heavy FB15k237-shaped batches, a few per cent on average).
  *   run_prefix  : int32 [E], by_src order: number of (source, destination) runs that start at or before each edge (inclusive
  *                 prefix count of `src or dst differs from the previous edge`); fixes every listed row's slot, so the list
  *                 is written without atomics or counters and the same way on every launch
  *   out         : [n_dst, n_query, 64], written completely
  *   row_list    : int32 scratch, at least n_query * (max runs of any source node + 1) entries
- *   list_offset : int32 scratch [n_query + 1];   const_tile : fp32 scratch [32 * 64], 16-byte aligned
+ *   list_offset : int32 scratch [n_query + 1]
  * Sum aggregation of DistMult messages with a FINITE relation table (as ultra_rspmm_frontier_f32).
  * ultra_first_layer_sparse_supported: the shapes this entry takes (message table of n_rel rows in LDS, n_query <= 128,
  * n_dst * n_query * 256 B < 4 GiB); otherwise call the two entries it fuses. */
@@ -193,7 +193,7 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
                                  const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
                                  const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
                                  const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                                 float *out, int32_t *row_list, int32_t *list_offset, float *const_tile, int64_t n_dst,
+                                 float *out, int32_t *row_list, int32_t *list_offset, int64_t n_dst,
                                  int64_t n_rel, void *stream);
 
 /* d_input of the FIRST layer's rspmm in training, at the rows that are used: that layer's input is the boundary

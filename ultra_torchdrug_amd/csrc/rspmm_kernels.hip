@@ -704,9 +704,8 @@ struct CombineParams {
 // ZOUT: the training forward also writes z = Linear(cat[input, update]) (the LayerNorm's input) so that the fused backward
 // loads it instead of recomputing it -- a third of that kernel's matrix work.
 // BND = 3: the first layer on the rows the frontier kernel touched only (a row list instead of consecutive rows; boundary
-// tables in LDS as in BND = 1).  BND = 4: one tile whose input and update rows are all zero -- what the epilogue makes of
-// a row the frontier did not touch; its first row is the constant the rest of the layer's output is filled with.  Both
-// run the same arithmetic on a row as every other form: a row's result does not depend on its tile mates.
+// tables in LDS as in BND = 1): the same arithmetic on a row as every other form -- a row's result does not depend on its
+// tile mates.  (What the epilogue makes of an untouched row is derived in const_fill_kernel, in this kernel's order.)
 template <bool PF, int BND = 0, bool ZOUT = false>
 __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(const CombineParams p) {
     extern __shared__ __attribute__((aligned(16))) float cb_lds[];
@@ -750,12 +749,6 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
     f32x4 pa[8], pb[8];     // PF: the staged rows of the tile about to be processed
     int rid[8];             // BND = 3: the listed row of every staged row (-1: none)
     auto fetch = [&](long long t) {
-        if constexpr (BND == 4) {                 // a tile of zeros
-            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { pa[q] = zero; pb[q] = zero; }
-            return;
-        }
         if constexpr (BND == 3) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -1671,8 +1664,8 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
     return ULTRA_OK;
 }
 
-// Sparse first layer of a Bellman-Ford in inference (see include/ultra_rspmm.h): constant tile -> broadcast fill + slot layout
-// -> frontier kernel (rows + their list) -> epilogue over the listed rows.  Four launches, all kernels (capturable).
+// Sparse first layer of a Bellman-Ford in inference (see include/ultra_rspmm.h): constant row broadcast + slot layout ->
+// frontier kernel (rows + their list) -> epilogue over the listed rows.  Three launches, all kernels (capturable).
 int ultra_first_layer_sparse_supported(int64_t n_dst, int64_t n_rel, int64_t n_query) {
     return n_query > 0 && n_query <= kCbLdsQueries && n_rel > 0 &&
            (size_t)n_rel * kTile * sizeof(float) <= (size_t)kMaxLdsBytes && n_dst > 0 &&
@@ -1683,46 +1676,44 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
                                  const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
                                  const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
                                  const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                                 float *out, int32_t *row_list, int32_t *list_offset, float *const_tile, int64_t n_dst,
+                                 float *out, int32_t *row_list, int32_t *list_offset, int64_t n_dst,
                                  int64_t n_rel, void *stream) {
     int rc = check_segments(by_src);
     if (rc) return rc;
     if (!ultra_first_layer_sparse_supported(n_dst, n_rel, n_query) || by_src->piece_len <= 0) return ULTRA_ERR_BAD_SHAPE;
     if (src_ptr == nullptr || fwd_rank == nullptr || run_prefix == nullptr || relation == nullptr || boundary_node == nullptr ||
         boundary_value == nullptr || weight == nullptr || bias == nullptr || out == nullptr || row_list == nullptr ||
-        list_offset == nullptr || const_tile == nullptr)
+        list_offset == nullptr)
         return ULTRA_ERR_NULL_POINTER;
     if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
     const long long F = n_query * 64;
-    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(relation) | reinterpret_cast<uintptr_t>(boundary_value) |
-         reinterpret_cast<uintptr_t>(const_tile)) & 15u) return ULTRA_ERR_BAD_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(relation) | reinterpret_cast<uintptr_t>(boundary_value)) & 15u)
+        return ULTRA_ERR_BAD_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     DeviceInfo *di = nullptr;
     rc = device_info(dev, &di);
     if (rc) return rc;
-    // (1) what the epilogue makes of an untouched row: one tile of zeros through the epilogue kernel itself
     CombineParams cp{};
-    cp.update = const_tile; cp.weight = weight; cp.bias = bias; cp.gamma = ln_weight; cp.beta = ln_bias;
-    cp.out = const_tile; cp.rows = kCbRows; cp.eps = ln_eps; cp.relu = relu; cp.shortcut = shortcut;
+    cp.weight = weight; cp.bias = bias; cp.gamma = ln_weight; cp.beta = ln_bias;
+    cp.eps = ln_eps; cp.relu = relu; cp.shortcut = shortcut;
     cp.in_bnode = boundary_node; cp.in_bvec = boundary_value; cp.rpn = (int)n_query;
     const size_t lds_cb = (size_t)(kCbWaves * kCbTileFloats + 128 + n_query * 65) * sizeof(float);
-    rc = ensure_lds_attribute(reinterpret_cast<const void *>(combine_kernel<false, 4>), lds_cb);
-    if (rc) return rc;
     rc = ensure_lds_attribute(reinterpret_cast<const void *>(combine_kernel<false, 3>), lds_cb);
     if (rc) return rc;
-    hipLaunchKernelGGL((combine_kernel<false, 4>), dim3(1), dim3(kCbWaves * 64), lds_cb, s, cp);
-    HIP_TRY(hipGetLastError());
-    // (2) the constant everywhere + the slot ranges of the row list
+    // (1) what the epilogue makes of an untouched row, everywhere + the slot ranges of the row list (const_fill_kernel)
     {
-        const long long n4 = (long long)n_dst * F / 4;
-        const unsigned blocks = (unsigned)((n4 + 256 * 8 - 1) / (256 * 8) < 4096 ? (n4 + 256 * 8 - 1) / (256 * 8) : 4096);
-        hipLaunchKernelGGL(const_fill_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<qf4 *>(out), n4,
-                           reinterpret_cast<const qf4 *>(const_tile), src_ptr, run_prefix, boundary_node, (int)n_query, list_offset);
+        ConstFillParams fp{};
+        fp.out = reinterpret_cast<qf4 *>(out); fp.n4 = (long long)n_dst * F / 4;
+        fp.bias = bias; fp.gamma = ln_weight; fp.beta = ln_bias; fp.eps = ln_eps; fp.relu = relu; fp.shortcut = shortcut;
+        fp.src_ptr = src_ptr; fp.run_prefix = run_prefix; fp.bnode = boundary_node; fp.n_query = (int)n_query;
+        fp.list_offset = list_offset;
+        const unsigned blocks = (unsigned)((fp.n4 + 256 * 8 - 1) / (256 * 8) < 4096 ? (fp.n4 + 256 * 8 - 1) / (256 * 8) : 4096);
+        hipLaunchKernelGGL(const_fill_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, fp);
         HIP_TRY(hipGetLastError());
     }
-    // (3) the frontier's rows over it, listed
+    // (2) the frontier's rows over it, listed
     FrontierParams p{};
     p.src_ptr = src_ptr; p.dst = by_src->node_a; p.rel = by_src->rel; p.weight = by_src->weight; p.fwd_rank = fwd_rank;
     p.relation = relation; p.bnode = boundary_node; p.bvec = boundary_value; p.out = out; p.F = F;
@@ -1736,7 +1727,7 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
     rc = by_src->weight == nullptr ? launch_with_lds(frontier_lds_kernel<true>, p, fgrid, msg_bytes, s, kFrontierLdsThreads)
                                    : launch_with_lds(frontier_lds_kernel<false>, p, fgrid, msg_bytes, s, kFrontierLdsThreads);
     if (rc) return rc;
-    // (4) the epilogue on the listed rows, in place
+    // (3) the epilogue on the listed rows, in place
     cp.update = out; cp.out = out; cp.rows = n_dst * n_query; cp.row_list = row_list; cp.list_count = list_offset + n_query;
     hipLaunchKernelGGL((combine_kernel<false, 3>), dim3((unsigned)(2 * di->n_cu)), dim3(kCbWaves * 64), lds_cb, s, cp);
     HIP_TRY(hipGetLastError());

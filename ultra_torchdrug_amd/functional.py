@@ -246,14 +246,13 @@ def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, l
     out = torch.empty(n_dst, n_query, 64, dtype=torch.float32, device=dev)
     row_list = torch.empty(n_query * (max_runs + 1), dtype=torch.int32, device=dev)
     list_offset = torch.empty(n_query + 1, dtype=torch.int32, device=dev)
-    const_tile = torch.empty(32 * 64, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.ultra_first_layer_sparse_f32(
             csr.by_src.pointer, src_ptr.data_ptr(), fwd_rank.data_ptr(), run_prefix.data_ptr(), relation.data_ptr(),
             b_node.data_ptr(), b_value.data_ptr(), n_query, weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
             ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
             ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
-            out.data_ptr(), row_list.data_ptr(), list_offset.data_ptr(), const_tile.data_ptr(), n_dst, n_rel, _stream()))
+            out.data_ptr(), row_list.data_ptr(), list_offset.data_ptr(), n_dst, n_rel, _stream()))
     return out
 
 
