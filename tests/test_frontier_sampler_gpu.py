@@ -83,13 +83,14 @@ def test_frontier_equals_full_kernel_on_dense_boundary(oracle, case):
 
 @pytest.mark.parametrize("case", ["uniform", "hub_split_rows_multi_relation", "weights", "kg_shape_32_queries", "self_loops"])
 @pytest.mark.parametrize("norm,relu,shortcut", [(True, True, True), (False, True, False), (True, False, True)])
-def test_sparse_first_layer_equals_frontier_plus_dense_epilogue(case, norm, relu, shortcut):
+def test_sparse_first_layer_equals_frontier_plus_dense_epilogue(monkeypatch, case, norm, relu, shortcut):
     """``ultra_first_layer_sparse_f32`` (round 4): the whole first layer with the epilogue on the rows the frontier reaches
     only, one constant vector broadcast everywhere else, must EQUAL ``ultra_rspmm_frontier_f32`` followed by the dense
     boundary-form epilogue bit for bit: isolated heads, repeated heads, self loops (the head's own row is then listed by a
     run, not by its spare slot), hubs with split rows, per-edge weights, and an FB15k237-shaped batch of 32 queries."""
     from ultra_torchdrug_amd import RelCSR, functional as UF
     dev = _dev()
+    monkeypatch.setattr(UF, "SPARSE_FIRST_LAYER_MIN_ROWS", 0)      # (the size heuristic would send the small graphs to the dense form)
     rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)
     opts = {}
     if case == "uniform":

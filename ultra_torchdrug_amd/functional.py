@@ -213,6 +213,10 @@ def rspmm_frontier(csr, relation, boundary):
 
 # Sparse first layer in inference (ultra_first_layer_sparse_f32).  ULTRA_SPARSE_FIRST_LAYER=0: frontier kernel + dense epilogue.
 SPARSE_FIRST_LAYER = __import__("os").environ.get("ULTRA_SPARSE_FIRST_LAYER", "1") != "0"
+# ... from this many output rows (nodes x queries) on: on a small dense graph a hub's out-edges reach most nodes, the list is
+# most of the rows and its indexed epilogue loses to the dense one (S-codexs, 65 k rows: 17 us against 13; S-fb15k237, 465 k rows:
+# 24 us against 108 on the hub-heaviest batch)
+SPARSE_FIRST_LAYER_MIN_ROWS = 1 << 17
 
 
 def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True,
@@ -228,7 +232,8 @@ def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, l
     n_dst, n_src, n_rel = csr.shape
     n_query = b_node.shape[0]
     lib = _lib.load()
-    if n_dst != n_src or not lib.ultra_first_layer_sparse_supported(n_dst, n_rel, n_query):
+    if (n_dst != n_src or n_dst * n_query < SPARSE_FIRST_LAYER_MIN_ROWS
+            or not lib.ultra_first_layer_sparse_supported(n_dst, n_rel, n_query)):
         return None
     F = n_query * 64
     b_value = b_value.contiguous()
