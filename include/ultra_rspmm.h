@@ -234,6 +234,27 @@ int ultra_rspmm_backward_accumulate_f32(const ultra_segments *by_src_host, const
                                         float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_src,
                                         int64_t n_dst, int64_t n_rel, int64_t F, int sum_op, int mul_op, void *stream);
 
+/* Backward of sum-aggregation when the caller KNOWS which rows carry gradient (ABI 6).  Same results as
+ * ultra_rspmm_backward_accumulate_f32(sum_op = add) bit for bit; the knowledge only lets the kernels skip gathers:
+ *   dst_active_bits : [F / 64][active_words] one bitmap over the destination nodes per 64-column tile (query block), bit v of
+ *                     tile b set where output_grad[v, tile b] may be non-zero -- the caller's promise that every other row of
+ *                     that tile IS zero (the LAST layer of a training step: the score head reads the layer's output at the
+ *                     candidate entities' rows only, /root/reference/ultra/model.py:177-183, so its gradient is zero elsewhere;
+ *                     ultra_node_bitmap builds the bitmaps from the candidate index grid); NULL: no such knowledge
+ *   src_active_node : [F / 64] for d_relation with mul = mul: the one source node per tile whose `input` row is non-zero (the
+ *                     FIRST layer: its input is the boundary, model.py:106-107,116-120); NULL: none
+ * An inactive edge contributes (+-0): its gathers are issued past the end of their buffer descriptors and return 0.0 without
+ * touching memory.  Used by the d_relation kernels (two gathers per edge: 30-45 % faster); d_input, which is bound by its row
+ * epilogue rather than by its gathers, and plans the masked kernels do not cover compute everything, as the unmasked entry does.
+ * ultra_node_bitmap: bits[b][w] over n_node nodes from t_index int64 [n_batch, per_row] (ids outside [0, n_node) are ignored);
+ * at most 512 Ki nodes (ULTRA_ERR_BAD_SHAPE beyond: go without the mask). */
+int ultra_rspmm_backward_active_f32(const ultra_segments *by_src, const ultra_segments *by_rel, const float *relation,
+                                    const float *input, const float *output_grad, const float *d_input_add, float *d_input,
+                                    float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_dst,
+                                    int64_t n_rel, int64_t F, int mul_op, const uint32_t *dst_active_bits, int64_t active_words,
+                                    const int32_t *src_active_node, void *stream);
+int ultra_node_bitmap(const int64_t *t_index, int64_t n_batch, int64_t per_row, int64_t n_node, uint32_t *bits, void *stream);
+
 /*
  * d_weight[e] = sum_f output_grad[dst_e, f] * [out == y] * (relation[r_e, f] MUL input[src_e, f])
  * (the value gradient torchdrug returns when sparse.requires_grad), edges in forward-plan order.

@@ -41,6 +41,10 @@ class AtenDefinition:
         return None
 
     @staticmethod
+    def candidate_rows(*args, **kwargs):
+        return None
+
+    @staticmethod
     def remove_triples(graph, h, t, r, n_base_rel):
         """``remove_easy_edges`` on the graph with inverse edges (``ultra/model.py:57-74,166``): a new, smaller graph."""
         n, rels = graph.num_node, graph.num_relation

@@ -114,6 +114,10 @@ class OracleFunctional:
         return None                                     # a hint for the HIP epilogue's backward; the oracle path computes every row
 
     @staticmethod
+    def candidate_rows(t_index, n_node):
+        return None                                     # likewise: a hint for the HIP rspmm backward
+
+    @staticmethod
     def statistics(values, repeated=None, repeat=0):
         """(norm, mean, std) of `values` with `repeated` taken `repeat` times, as the reference computes them: ATen
         reductions over the materialised tensor (model.py:158-160,178-181)."""
@@ -148,7 +152,8 @@ class OracleFunctional:
         return out + (add_rows if boundary is None else self._dense_boundary(boundary, out.shape[0]))
 
     def sum_layer(self, csr, relation, input, boundary_dense, boundary_sparse, mul, weight, bias, ln_weight=None,
-                  ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False, input_is_boundary=False, grad_tiles=None):
+                  ln_bias=None, ln_eps=1e-5, relu=True, shortcut=False, input_is_boundary=False, grad_tiles=None,
+                  grad_rows=None):
         """The layer the reference's way, op by op (layer.py:298-392, model.py:126-127)."""
         shape = input.shape
         if boundary_sparse is not None:

@@ -26,6 +26,10 @@ def _dev():
     return torch.device("cuda:0")
 
 
+def _t(a):
+    return torch.from_numpy(np.asarray(a)).to(_dev())
+
+
 def _relcsr(g, n_dst, n_src, n_rel):
     from ultra_torchdrug_amd import RelCSR
     dev = _dev()
@@ -570,3 +574,66 @@ def test_hot_row_cache_variant_matches_plain_variant(oracle):
         da, ra = UF.rspmm_backward(hot, t(relation), t(x), None, t(grad), "add", m)
         db, rb = UF.rspmm_backward(cold, t(relation), t(x), None, t(grad), "add", m)
         assert torch.equal(da, db) and torch.equal(ra, rb)
+
+
+@pytest.mark.parametrize("case", ["kg_unit_weights", "kg_zero_weight_edges", "skewed_weights_hub_split"])
+@pytest.mark.parametrize("mul", ["mul", "add"])
+def test_backward_with_activity_masks_equals_the_full_backward(case, mul):
+    """Round 4: ``ultra_rspmm_backward_active_f32`` -- the backward of sum-aggregation told WHICH gradient rows (last layer of a
+    training step: the candidates' rows, one bitmap per 64-column query block) or WHICH input row per block (first layer: the
+    boundary node) can be non-zero.  Edges that can only add zero issue their gathers past the buffer descriptors (0.0, no
+    memory traffic); d_input (alone and accumulated into a given gradient) and d_relation must EQUAL the unmasked backward bit
+    for bit on operands that keep the promise."""
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    dev = _dev()
+    if case == "skewed_weights_hub_split":
+        n, r = 900, 14
+        g = random_graph(seed=8, n_node=n, n_edge=30000, n_rel=r, skew=True, weights=True, hub_row=5, hub_edges=4000)
+        opts = dict(chunk_edges=16, piece_len=64)
+    else:
+        n, r = 14541, 474
+        g = kg_graph(1024, n, 272115, 237)
+        opts = {}
+        if case == "kg_zero_weight_edges":          # the training step's edge removal: per-edge weights, a few of them 0
+            rng_w = np.random.default_rng(3)
+            g["w"] = (rng_w.random(len(g["dst"])) > 0.01).astype(np.float32)
+    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), None if g["w"] is None else _t(g["w"]), n, n, r, **opts)
+    B, K = 16, 129
+    F = B * 64
+    gen = torch.Generator(device=dev).manual_seed(zlib.crc32((case + mul).encode()) % 1000)
+    relation = torch.randn(r, F, device=dev, generator=gen)
+    x = torch.randn(n, F, device=dev, generator=gen)
+    already = torch.randn(n, F, device=dev, generator=gen)
+
+    # ---- last layer: the gradient is non-zero at the candidates' (node, query) rows only
+    t_index = torch.randint(0, n, (B, K), device=dev, generator=gen)
+    t_index[:, 0] = torch.bincount(csr.dst, minlength=n).argmax()                      # a hub among the candidates
+    bits = UF.candidate_rows(t_index, n)
+    assert bits is not None and bits.shape == (B, (n + 31) // 32) and bits.dtype == torch.int32
+    member = torch.zeros(B, n, dtype=torch.bool, device=dev)
+    member[torch.arange(B, device=dev).unsqueeze(-1), t_index] = True
+    words = bits.view(B, -1, 1).to(torch.int64) & 0xffffffff
+    unpacked = ((words >> torch.arange(32, device=dev)) & 1).bool().flatten(1)[:, :n]
+    assert torch.equal(unpacked, member), "node bitmap differs from the candidate sets"
+    grad = torch.randn(n, B, 64, device=dev, generator=gen) * member.t().unsqueeze(-1)   # zero rows elsewhere
+    grad = grad.flatten(1).contiguous()
+    want_dx, want_drel = UF.rspmm_backward(csr, relation, x, None, grad, "add", mul)
+    got_dx, got_drel = UF.rspmm_backward(csr, relation, x, None, grad, "add", mul, active_dst=bits)
+    assert torch.equal(got_dx, want_dx) and torch.equal(got_drel, want_drel)
+    want_acc, _ = UF.rspmm_backward(csr, relation, x, None, grad, "add", mul, need_relation=False, d_input_add=already.clone())
+    got_acc, _ = UF.rspmm_backward(csr, relation, x, None, grad, "add", mul, need_relation=False, d_input_add=already.clone(),
+                                   active_dst=bits)
+    assert torch.equal(got_acc, want_acc)
+
+    # ---- first layer: the input is the boundary -- zero outside row node[b] of block b (d_relation, mul = mul only)
+    if mul == "mul":
+        deg_out = torch.bincount(csr.src, minlength=n)
+        node = torch.randint(0, n, (B,), device=dev, generator=gen).to(torch.int32)
+        node[0], node[1] = int(deg_out.argmax()), int(deg_out.argmin())                # a hub head and a (nearly) isolated one
+        boundary = torch.zeros(n, B, 64, device=dev)
+        boundary[node.long(), torch.arange(B, device=dev)] = torch.randn(B, 64, device=dev, generator=gen)
+        boundary = boundary.flatten(1).contiguous()
+        dense_grad = torch.randn(n, F, device=dev, generator=gen)
+        _, want = UF.rspmm_backward(csr, relation, boundary, None, dense_grad, "add", "mul", need_input=False)
+        _, got = UF.rspmm_backward(csr, relation, boundary, None, dense_grad, "add", "mul", need_input=False, active_src=node)
+        assert torch.equal(got, want)

@@ -8,7 +8,7 @@ optional functions: a backend is an object with this complete interface
     generalized_rspmm, rspmm_forward, rspmm_sum_plus, rspmm_frontier, frontier_supported, first_layer_forward, sum_layer,
     remove_triples
     combine, linear_supported, linear_forward, relation_project, relation_project_train, score_all_entities
-    filtered_rank, filtered_rank_keys, strict_negatives, statistics, bce_adversarial_loss, candidate_tiles,
+    filtered_rank, filtered_rank_keys, strict_negatives, statistics, bce_adversarial_loss, candidate_tiles, candidate_rows,
     score_candidates_supported, score_candidates
 
 The parity tests install a second implementation of the same interface (``tests/oracle_ops.py``: the CPU oracle

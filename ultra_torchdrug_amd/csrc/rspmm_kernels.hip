@@ -82,6 +82,10 @@ struct KParams {
     int split;
     int n_slots;
     int blocks_per_label;
+    // backward, optional (see quad.inc ACT): which gradient / input rows are non-zero per 64-column tile
+    const uint32_t *act_bits;   // [n_tiles][act_words] bitmap over destination nodes, or NULL
+    int act_words;
+    const int32_t *act_node;    // [n_tiles] the one source node whose input row is non-zero, or NULL
 };
 
 struct FixParams {
@@ -332,6 +336,9 @@ struct PParams {
     int n_slots;
     int blocks_per_label;
     int concurrent;          // quad_kernel: teams per label working on different column tiles at once (0 / 1: none)
+    const uint32_t *act_bits;   // quad_kernel ACT = 1 / 2: [n_tiles][act_words]
+    int act_words;
+    const int32_t *act_node;    // quad_kernel ACT = 3: [n_tiles]
 };
 
 // VAR 0: node id inside the packed word, relation tile in LDS (KG-sized graphs).
@@ -1124,6 +1131,20 @@ int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, int var
 
 template <int KIND, int SUM, int MUL>
 int launch_quad_w(const PParams &p, bool unit_w, bool x_lds, int grid, size_t lds, hipStream_t stream) {
+    // activity masks (see quad.inc ACT): d_relation only.  The d_input form (ACT = 1) was built and measured: that kernel is
+    // bound by its per-row epilogue (read-modify-write of the gradient it accumulates into) and per-edge issue, not by its
+    // gathers -- 137 vs 138 us on the FB15k237-shaped graph, 156 vs 148 us on the WN18RR-shaped one with the mask -- so it is
+    // not dispatched; d_relation (two gathers per edge) gains 30-45 %.
+    if constexpr (KIND == KIND_DREL) {
+        if (p.act_bits != nullptr && !x_lds) {
+            if (unit_w) return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, false, kQuadU, 2>, p, grid, lds, stream);
+            return launch_with_lds(quad_kernel<KIND, SUM, MUL, false, false, kQuadUW, 2>, p, grid, lds, stream);
+        }
+        if (p.act_node != nullptr && !x_lds) {
+            if (unit_w) return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, false, kQuadU, 3>, p, grid, lds, stream);
+            return launch_with_lds(quad_kernel<KIND, SUM, MUL, false, false, kQuadUW, 3>, p, grid, lds, stream);
+        }
+    }
     if constexpr (KIND != KIND_DREL || MUL == ULTRA_MUL_MUL) {       // d_relation of mul = add reads no `input` row
         if (x_lds) {
             if (unit_w) return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, true, kQuadUX>, p, grid, lds, stream);
@@ -1152,7 +1173,7 @@ int launch_quad(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_ld
         return launch_quad_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, x_lds, grid, lds, stream);
     } else {
         if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream);
-        return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, false, grid, kLdsHeader, stream);
+        return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, false, grid, p.act_bits != nullptr ? lds : (size_t)kLdsHeader, stream);
     }
     return ULTRA_ERR_BAD_OP;
 }
@@ -1414,7 +1435,19 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
                         conc = want;
                 }
                 q.concurrent = conc;
-                rc = launch_quad<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var == 1, grid, kLdsHeader + lds_bytes, stream);
+                // activity masks of the backward (quad.inc ACT): only where the gathered matrix is not staged in LDS, the
+                // bitmap fits behind the tables and a column tile is a query block
+                size_t act_bytes = 0;
+                if (KIND == KIND_DREL && var == 0 && F % kTile == 0) {
+                    if (p.act_bits != nullptr && p.act_words > 0 && lds_bytes + (size_t)p.act_words * 4 <= (size_t)kMaxLdsBytes) {
+                        q.act_bits = p.act_bits;
+                        q.act_words = p.act_words;
+                        act_bytes = (size_t)p.act_words * 4;
+                    } else if (KIND == KIND_DREL && p.act_node != nullptr && mul_op == ULTRA_MUL_MUL) {
+                        q.act_node = p.act_node;      // (mul = add: d_relation does not depend on the input rows)
+                    }
+                }
+                rc = launch_quad<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var == 1, grid, kLdsHeader + lds_bytes + act_bytes, stream);
             }
             if (!quad) rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var, grid, kLdsHeader + lds_bytes, stream);
             if (rc) return rc;
@@ -1808,6 +1841,37 @@ int ultra_rspmm_backward_accumulate_f32(const ultra_segments *by_src, const ultr
         p.grad = output_grad;
         p.out = d_relation;
         int rc = run_plan<KIND_DREL>(by_rel, p, n_src, n_dst, n_rel, F, sum_op, mul_op, false, workspace, workspace_bytes, s);
+        if (rc) return rc;
+    }
+    return ULTRA_OK;
+}
+
+// Backward of sum-aggregation with the caller's knowledge of WHICH rows carry gradient (see include/ultra_rspmm.h).
+int ultra_rspmm_backward_active_f32(const ultra_segments *by_src, const ultra_segments *by_rel, const float *relation,
+                                    const float *input, const float *output_grad, const float *d_input_add, float *d_input,
+                                    float *d_relation, void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_dst,
+                                    int64_t n_rel, int64_t F, int mul_op, const uint32_t *dst_active_bits, int64_t active_words,
+                                    const int32_t *src_active_node, void *stream) {
+    if (output_grad == nullptr || relation == nullptr || input == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (dst_active_bits != nullptr && (active_words < (n_dst + 31) / 32 || active_words > 0x7fffffffLL)) return ULTRA_ERR_BAD_SHAPE;
+    if ((dst_active_bits != nullptr || src_active_node != nullptr) && F % kTile != 0) return ULTRA_ERR_BAD_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d_input != nullptr) {
+        if (by_src == nullptr) return ULTRA_ERR_NULL_POINTER;
+        KParams p{};
+        p.relation = relation; p.input = input; p.grad = output_grad; p.out = d_input; p.add_rows = d_input_add;
+        p.act_bits = dst_active_bits; p.act_words = (int)active_words;
+        int rc = run_plan<KIND_DX>(by_src, p, n_dst, 0, n_rel, F, ULTRA_SUM_ADD, mul_op, mul_op == ULTRA_MUL_MUL, workspace,
+                                   workspace_bytes, s);
+        if (rc) return rc;
+    }
+    if (d_relation != nullptr) {
+        if (by_rel == nullptr) return ULTRA_ERR_NULL_POINTER;
+        if (by_rel->n_edges > 0 && by_rel->node_b == nullptr) return ULTRA_ERR_NULL_POINTER;
+        KParams p{};
+        p.relation = relation; p.input = input; p.grad = output_grad; p.out = d_relation;
+        p.act_bits = dst_active_bits; p.act_words = (int)active_words; p.act_node = src_active_node;
+        int rc = run_plan<KIND_DREL>(by_rel, p, n_src, n_dst, n_rel, F, ULTRA_SUM_ADD, mul_op, false, workspace, workspace_bytes, s);
         if (rc) return rc;
     }
     return ULTRA_OK;

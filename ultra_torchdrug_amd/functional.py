@@ -21,7 +21,7 @@ import torch
 from . import _lib, _torch_ext
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "first_layer_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "candidate_tiles", "score_candidates", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "first_layer_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "candidate_tiles", "candidate_rows", "score_candidates", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -261,15 +261,72 @@ def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, l
     return out
 
 
+# Training: the backward's gathers skipped where the caller knows the gradient (last layer) or the input (first layer) rows are
+# zero -- see rspmm_backward(active_dst=, active_src=).  ULTRA_ACTIVE_ROW_BACKWARD=0: every edge gathers.
+ACTIVE_ROW_BACKWARD = __import__("os").environ.get("ULTRA_ACTIVE_ROW_BACKWARD", "1") != "0"
+
+
+def candidate_rows(t_index, n_node):
+    """Per query ``b`` the set ``{t_index[b, j]}`` as a bitmap over the nodes, int32 ``(B, ceil(N / 32))`` -- the rows of the LAST
+    layer's output the score head reads (``ultra/model.py:177-183``), i.e. the only rows where that output's gradient is
+    non-zero.  One launch, static shapes (capturable).  ``None`` beyond 512 Ki nodes or when the masked backward is switched off."""
+    if not ACTIVE_ROW_BACKWARD or not t_index.is_cuda or t_index.dtype != torch.int64 or t_index.dim() != 2:
+        return None
+    n_words = (int(n_node) + 31) // 32
+    if n_words > 16384 or n_words == 0:
+        return None
+    t_index = t_index.contiguous()
+    bits = torch.empty(t_index.shape[0], n_words, dtype=torch.int32, device=t_index.device)
+    lib = _lib.load()
+    with torch.cuda.device(t_index.device):
+        _lib.check(lib.ultra_node_bitmap(t_index.data_ptr(), t_index.shape[0], t_index.shape[1], int(n_node), bits.data_ptr(),
+                                         _stream()))
+    return bits
+
+
 def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mul", need_input=True,
-                   need_relation=True, d_input_add=None):
+                   need_relation=True, d_input_add=None, active_dst=None, active_src=None):
     """``(d_input, d_relation)``.  ``d_input_add`` (sum aggregation only): a contiguous ``(N_src, F)`` gradient the
     same rows already hold (from the layer's dense epilogue); the edge gradient is accumulated INTO it inside the
-    kernel's row epilogue and the same tensor is returned -- no separate add pass."""
+    kernel's row epilogue and the same tensor is returned -- no separate add pass.
+    ``active_dst`` (sum aggregation): int32 ``(F / 64, ceil(N_dst / 32))`` bitmaps (:func:`candidate_rows`) -- the caller's
+    promise that ``output_grad[v, block b]`` is zero wherever bit ``v`` of row ``b`` is clear; ``active_src`` (sum, mul = mul):
+    int32 ``(F / 64,)`` -- the promise that ``input[u, block b]`` is zero unless ``u == active_src[b]``.  Same results bit for bit;
+    the kernels skip the gathers of edges that can only add zero (``ultra_rspmm_backward_active_f32``)."""
     sum_op, mul_op = _ops(sum, mul)
     relation, input, output_grad = relation.contiguous(), input.contiguous(), output_grad.contiguous()
     F = input.shape[1]
     dev = input.device
+    if (ACTIVE_ROW_BACKWARD and sum == "add" and F % 64 == 0 and F > 0 and (need_input or need_relation)
+            and (active_dst is not None or (active_src is not None and mul == "mul"))):
+        n_tiles = F // 64
+        if active_dst is not None and (active_dst.dtype != torch.int32 or not active_dst.is_contiguous() or active_dst.device != dev
+                                       or tuple(active_dst.shape) != (n_tiles, (csr.shape[0] + 31) // 32)):
+            raise RuntimeError("rspmm_backward: active_dst must be contiguous int32 (%d, %d) on %s"
+                               % (n_tiles, (csr.shape[0] + 31) // 32, dev))
+        if active_src is not None and (active_src.dtype != torch.int32 or not active_src.is_contiguous() or active_src.device != dev
+                                       or tuple(active_src.shape) != (n_tiles,)):
+            raise RuntimeError("rspmm_backward: active_src must be contiguous int32 (%d,) on %s" % (n_tiles, dev))
+        if d_input_add is not None and (not need_input or not d_input_add.is_contiguous() or d_input_add.shape != input.shape
+                                        or d_input_add.dtype != torch.float32):
+            raise RuntimeError("d_input_add: contiguous fp32 tensor of input's shape, sum aggregation, with need_input")
+        d_input = (d_input_add if d_input_add is not None else torch.empty_like(input)) if need_input else None
+        d_relation = torch.empty_like(relation) if need_relation else None
+        by_src = csr.by_src if need_input else None
+        by_rel = csr.by_rel if need_relation else None
+        lib = _lib.load()
+        n_ws = max(by_src.n_pieces if by_src is not None else 0, by_rel.n_pieces if by_rel is not None else 0) * F
+        ws = torch.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.ultra_rspmm_backward_active_f32(
+                by_src.pointer if by_src is not None else None, by_rel.pointer if by_rel is not None else None,
+                relation.data_ptr(), input.data_ptr(), output_grad.data_ptr(),
+                d_input_add.data_ptr() if d_input_add is not None else None,
+                d_input.data_ptr() if d_input is not None else None, d_relation.data_ptr() if d_relation is not None else None,
+                ws.data_ptr() if ws is not None else None, n_ws * 4, csr.shape[1], csr.shape[0], csr.shape[2], F, mul_op,
+                active_dst.data_ptr() if active_dst is not None else None, active_dst.shape[1] if active_dst is not None else 0,
+                active_src.data_ptr() if (active_src is not None and mul == "mul") else None, _stream()))
+        return d_input, d_relation
     if d_input_add is not None and (not need_input or sum != "add" or not d_input_add.is_contiguous()
                                     or d_input_add.shape != input.shape or d_input_add.dtype != torch.float32):
         raise RuntimeError("d_input_add: contiguous fp32 tensor of input's shape, sum aggregation, with need_input")
@@ -999,7 +1056,7 @@ class _SumLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, csr, relation, input, add_rows, b_node, b_value, mul, weight, bias, ln_weight, ln_bias, ln_eps,
-                relu, shortcut, input_is_boundary=False, grad_tiles=None):
+                relu, shortcut, input_is_boundary=False, grad_tiles=None, grad_rows=None):
         shape = input.shape                                      # (N, B, 64)
         flat = input.flatten(1)
         boundary = None if b_node is None else (b_node, b_value.detach())
@@ -1024,6 +1081,8 @@ class _SumLayerFunction(torch.autograd.Function):
         ctx.boundary_rows_only = first_layer
         # last layer: the caller's word that the output's gradient is zero outside these 32-row tiles (see sum_layer)
         ctx.grad_tiles = grad_tiles if (grad_tiles is not None and SPARSE_LAST_LAYER_BACKWARD) else None
+        # ... and outside these (node, query) rows (candidate_rows): the rspmm backward gathers d_update rows there only
+        ctx.grad_rows = grad_rows
         ctx.flags = (float(ln_eps), bool(relu), bool(shortcut))
         ctx.save_for_backward(relation, input, update, weight, bias, ln_weight, ln_bias, z)
         return out
@@ -1062,13 +1121,15 @@ class _SumLayerFunction(torch.autograd.Function):
         # the edge gradient accumulates into the epilogue's d_input (same buffer) inside the rspmm backward
         flat_du = d_update.flatten(1)
         if ctx.boundary_rows_only and needs[2]:
+            # first layer: the input is zero outside row b_node[q] of block q -- d_relation needs that node's out-edges only
             _, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,
-                                           need_input=False, need_relation=needs[1])
+                                           need_input=False, need_relation=needs[1], active_dst=ctx.grad_rows,
+                                           active_src=ctx.b_node)
             d_in = rspmm_backward_boundary_rows(ctx.csr, relation.contiguous(), flat_du, ctx.b_node, d_input.flatten(1), ctx.mul)
         else:
             d_in, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,
                                               need_input=needs[2], need_relation=needs[1],
-                                              d_input_add=d_input.flatten(1) if needs[2] else None)
+                                              d_input_add=d_input.flatten(1) if needs[2] else None, active_dst=ctx.grad_rows)
         d_add = d_update if (ctx.has_add and needs[3]) else None
         d_value = None
         if ctx.b_node is not None and needs[5]:
@@ -1079,23 +1140,25 @@ class _SumLayerFunction(torch.autograd.Function):
                                                               d_value.data_ptr(), _stream()))
         return (None, d_relation, d_in.view(shape) if d_in is not None else None, d_add, None, d_value, None,
                 d_weight if needs[7] else None, d_bias if needs[8] else None, d_g if (has_ln and needs[9]) else None,
-                d_b if (has_ln and needs[10]) else None, None, None, None, None, None)
+                d_b if (has_ln and needs[10]) else None, None, None, None, None, None, None)
 
 
 def sum_layer(csr, relation, input, boundary_dense, boundary_sparse, mul, weight, bias, ln_weight=None, ln_bias=None,
-              ln_eps=1e-5, relu=True, shortcut=False, input_is_boundary=False, grad_tiles=None):
+              ln_eps=1e-5, relu=True, shortcut=False, input_is_boundary=False, grad_tiles=None, grad_rows=None):
     """A whole sum-aggregation layer for TRAINING as one autograd node (see :class:`_SumLayerFunction`):
     ``[input +] relu(LN(Linear(cat[input, rspmm(csr, relation, input) + boundary])))``.  ``input``: ``(N, B, 64)``;
     ``relation``: ``(R, B * 64)``; the boundary either dense ``(N, B, 64)`` or sparse ``(node int32 (B,), value (B, 64))``.
     ``input_is_boundary``: the caller's word that ``input`` is the boundary (first layer).  ``grad_tiles``: int32 tile ids
     (row ``// 32`` of the ``(N * B, 64)`` view, ascending, ``-1`` padding) -- the caller's word that the gradient arriving at
     this layer's OUTPUT is zero outside those tiles (the last layer, whose output is read at the candidate entities' rows only,
-    ``ultra/model.py:177-183``; see :func:`candidate_tiles`): the epilogue's backward then computes those tiles alone."""
+    ``ultra/model.py:177-183``; see :func:`candidate_tiles`): the epilogue's backward then computes those tiles alone.
+    ``grad_rows``: the same promise per (node, query) row as bitmaps (:func:`candidate_rows`): the rspmm backward of the layer
+    then gathers gradient rows at those destinations only."""
     _check_dense(csr, relation, input.flatten(1))
     b_node, b_value = (None, None) if boundary_sparse is None else boundary_sparse
     add_rows = boundary_dense if boundary_sparse is None else None
     return _SumLayerFunction.apply(csr, relation, input, add_rows, b_node, b_value, mul, weight, bias, ln_weight, ln_bias,
-                                   ln_eps, relu, shortcut, input_is_boundary, grad_tiles)
+                                   ln_eps, relu, shortcut, input_is_boundary, grad_tiles, grad_rows)
 
 
 def rspmm_sum_plus(sparse, relation, input, add_rows, mul="mul", boundary=None):

@@ -142,12 +142,12 @@ class _RelationalConvBase(nn.Module):
     def _relation_table(self, graph, batch_size):
         raise NotImplementedError
 
-    def forward(self, graph, input, shortcut=False, input_is_boundary=False, grad_tiles=None):
+    def forward(self, graph, input, shortcut=False, input_is_boundary=False, grad_tiles=None, grad_rows=None):
         """``MessagePassingBase.forward``: ``combine(input, message_and_aggregate(graph, input))``.  ``shortcut``
         additionally adds ``input`` (the caller's ``hidden + layer_input``, ``ultra/model.py:126-127``) so that the
         inference path can run combine + shortcut as ONE HIP kernel.  ``input_is_boundary``: the caller's promise that
         ``input`` is ``graph.boundary`` (the first layer of a Bellman-Ford, ``ultra/model.py:116-120``)."""
-        fused = self._sum_layer(graph, input, shortcut, input_is_boundary, grad_tiles)
+        fused = self._sum_layer(graph, input, shortcut, input_is_boundary, grad_tiles, grad_rows)
         if fused is not None:
             return fused
         update = self.message_and_aggregate(graph, input, input_is_boundary=input_is_boundary)
@@ -160,7 +160,7 @@ class _RelationalConvBase(nn.Module):
         output = self.combine(input, update)
         return output + input if shortcut else output
 
-    def _sum_layer(self, graph, input, shortcut, input_is_boundary=False, grad_tiles=None):
+    def _sum_layer(self, graph, input, shortcut, input_is_boundary=False, grad_tiles=None, grad_rows=None):
         """Training with summed messages and the shipped 64 -> 64 epilogue: the whole layer as one autograd node
         (``backend.sum_layer``), so that the two gradients of ``input`` (through the edges, through the epilogue) are
         produced by one kernel sequence without an add pass.  ``None``: not applicable, take the general path."""
@@ -182,7 +182,7 @@ class _RelationalConvBase(nn.Module):
                              self.message2mul[self.message_func], self.linear.weight, self.linear.bias,
                              ln.weight if ln else None, ln.bias if ln else None, ln.eps if ln else 1e-5,
                              relu=self.activation is F.relu, shortcut=shortcut, input_is_boundary=input_is_boundary,
-                             grad_tiles=grad_tiles)
+                             grad_tiles=grad_tiles, grad_rows=grad_rows)
 
     def _no_grad(self, *tensors):
         return not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors if t is not None)

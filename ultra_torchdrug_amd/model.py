@@ -152,9 +152,11 @@ class TransferNBFNet(nn.Module):
                 late_graph.relation_tables[id(conv)] = tables[id(conv)].view_as(tables[id(conv)])
         # training: the caller reads the LAST layer's output at rows (grad_candidates[b, j], b) only -- the epilogue's
         # backward of that layer then works on the tiles of those rows alone (functional.sum_layer)
-        last_tiles = None
+        last_tiles = last_rows = None
         if grad_candidates is not None and torch.is_grad_enabled() and not want_feature and not separate_grad:
             last_tiles = backend.get().candidate_tiles(grad_candidates, bs, graph.num_node)
+            # ... and the rspmm backward of that layer gathers gradient rows at the candidates' (node, query) rows alone
+            last_rows = backend.get().candidate_rows(grad_candidates, graph.num_node)
         for position, conv in enumerate(self.layers):
             step_graph = graph if (cut is None or position < cut) else late_graph
             if cut is not None and position == cut:
@@ -168,7 +170,8 @@ class TransferNBFNet(nn.Module):
             hidden = conv(step_graph, layer_input,
                           shortcut=self.short_cut and conv.output_dim == layer_input.shape[-1],
                           input_is_boundary=layer_input is boundary,
-                          grad_tiles=last_tiles if position == len(self.layers) - 1 else None)
+                          grad_tiles=last_tiles if position == len(self.layers) - 1 else None,
+                          grad_rows=last_rows if position == len(self.layers) - 1 else None)
             hiddens.append(hidden)
             step_graphs.append(step_graph)
             layer_input = hidden
