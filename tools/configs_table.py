@@ -22,8 +22,13 @@ def main(path, out):
                    % (c["operator_fwd_us"], c["operator_bwd_us"], s["median_ms"], s["p10_ms"], s["p90_ms"], s["max_ms"], s["n"]))
         elif k == 4:
             s = c["step"]
-            got = ("captured step median %.1f ms (min %.1f, max %.1f; graphs drawn %s); eager step %.1f ms"
-                   % (s["median_ms"], s["min_ms"], s["max_ms"], c["graphs_drawn"], c["eager_step_ms"]))
+            got = ("captured step median %.1f ms (min %.1f, max %.1f; graphs drawn on rank 0: %s); %d rank(s): %.1f ms per step max over ranks"
+                   % (s["median_ms"], s["min_ms"], s["max_ms"], c.get("graphs_drawn_rank0", c.get("graphs_drawn", "?")), c.get("n_gpus", 1),
+                      c.get("step_ms_max_over_ranks", s["median_ms"])))
+            if "eager_step_ms" in c:
+                got += "; eager step %.1f ms" % c["eager_step_ms"]
+            if "allreduce_exposed_ms_per_step" in c:
+                got += "; gradient all-reduce exposed %.2f ms per step (mode %s)" % (c["allreduce_exposed_ms_per_step"], c.get("step_mode"))
         else:
             got = "operator fwd %.2f ms = %.2e edges/s = %.3f of the 8 TB/s HBM peak" % (c["operator_fwd_ms"], c["edges_per_s"], c["frac_of_hbm_peak"])
         rows.append("| %d | %s | %s | %s |" % (k, c["name"], c["shape"], got))
