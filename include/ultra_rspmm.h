@@ -183,7 +183,8 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
  *                 prefix count of `src or dst differs from the previous edge`); fixes every listed row's slot, so the list
  *                 is written without atomics or counters and the same way on every launch
  *   out         : [n_dst, n_query, 64], written completely
- *   row_list    : int32 scratch, at least n_query * (max runs of any source node + 1) entries
+ *   row_list    : int32 scratch of row_list_len entries, at least n_query * (max runs of any source node + 1) (slots beyond
+ *                 row_list_len are neither written nor read: rows whose slot does not fit would keep the constant -- size it)
  *   list_offset : int32 scratch [n_query + 1]
  * Sum aggregation of DistMult messages with a FINITE relation table (as ultra_rspmm_frontier_f32).
  * ultra_first_layer_sparse_supported: the shapes this entry takes (message table of n_rel rows in LDS, n_query <= 128,
@@ -193,7 +194,7 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
                                  const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
                                  const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
                                  const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                                 float *out, int32_t *row_list, int32_t *list_offset, int64_t n_dst,
+                                 float *out, int32_t *row_list, int64_t row_list_len, int32_t *list_offset, int64_t n_dst,
                                  int64_t n_rel, void *stream);
 
 /* d_input of the FIRST layer's rspmm in training, at the rows that are used: that layer's input is the boundary

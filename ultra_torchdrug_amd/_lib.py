@@ -155,7 +155,7 @@ def load():
     lib.ultra_first_layer_sparse_supported.restype = i32
     lib.ultra_first_layer_sparse_supported.argtypes = [i64, i64, i64]
     lib.ultra_first_layer_sparse_f32.restype = i32
-    lib.ultra_first_layer_sparse_f32.argtypes = [seg, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp,
+    lib.ultra_first_layer_sparse_f32.argtypes = [seg, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, i64, vp,
                                                  i64, i64, vp]
     lib.ultra_rspmm_backward_f32.restype = i32
     lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, i32, i32, vp]

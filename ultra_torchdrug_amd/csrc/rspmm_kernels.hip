@@ -698,6 +698,7 @@ struct CombineParams {
     // query, -1 = empty slot), read from and written back to `update` / `out` at those rows; `rows` bounds the row ids
     const int32_t *row_list;
     const int32_t *list_count;
+    int list_len;                // entries the list holds (the count is clamped to it)
 };
 
 // PF = true (large inputs): one wave per SIMD (up to 512 VGPRs); the NEXT tile's 16 KiB are fetched into registers
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
     float *tile = cb_lds + wl * kCbTileFloats;
     const int i = lane & 31, h = lane >> 5;
     int n_list = 0;
-    if constexpr (BND == 3) n_list = uniform(p.list_count[0]);
+    if constexpr (BND == 3) n_list = min(uniform(p.list_count[0]), p.list_len);
     const long long n_tiles = BND == 3 ? ((long long)n_list + kCbRows - 1) / kCbRows : (p.rows + kCbRows - 1) / kCbRows;
     const long long wave_global = (long long)blockIdx.x * kCbWaves + wl;
     const long long wave_total = (long long)gridDim.x * kCbWaves;
@@ -1709,11 +1710,13 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
                                  const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
                                  const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
                                  const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                                 float *out, int32_t *row_list, int32_t *list_offset, int64_t n_dst,
+                                 float *out, int32_t *row_list, int64_t row_list_len, int32_t *list_offset, int64_t n_dst,
                                  int64_t n_rel, void *stream) {
     int rc = check_segments(by_src);
     if (rc) return rc;
-    if (!ultra_first_layer_sparse_supported(n_dst, n_rel, n_query) || by_src->piece_len <= 0) return ULTRA_ERR_BAD_SHAPE;
+    if (!ultra_first_layer_sparse_supported(n_dst, n_rel, n_query) || by_src->piece_len <= 0 || row_list_len < n_query ||
+        row_list_len > 0x7fffffffLL)
+        return ULTRA_ERR_BAD_SHAPE;
     if (src_ptr == nullptr || fwd_rank == nullptr || run_prefix == nullptr || relation == nullptr || boundary_node == nullptr ||
         boundary_value == nullptr || weight == nullptr || bias == nullptr || out == nullptr || row_list == nullptr ||
         list_offset == nullptr)
@@ -1741,7 +1744,7 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
         fp.out = reinterpret_cast<qf4 *>(out); fp.n4 = (long long)n_dst * F / 4;
         fp.bias = bias; fp.gamma = ln_weight; fp.beta = ln_bias; fp.eps = ln_eps; fp.relu = relu; fp.shortcut = shortcut;
         fp.src_ptr = src_ptr; fp.run_prefix = run_prefix; fp.bnode = boundary_node; fp.n_query = (int)n_query;
-        fp.list_offset = list_offset;
+        fp.list_offset = list_offset; fp.list_len = (int)row_list_len;
         const unsigned blocks = (unsigned)((fp.n4 + 256 * 8 - 1) / (256 * 8) < 4096 ? (fp.n4 + 256 * 8 - 1) / (256 * 8) : 4096);
         hipLaunchKernelGGL(const_fill_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, fp);
         HIP_TRY(hipGetLastError());
@@ -1753,7 +1756,7 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
     p.piece_len = (int)by_src->piece_len; p.n_rel = (int)n_rel; p.piece_shift = -1;
     for (int sh = 0; sh < 31; ++sh)
         if ((1LL << sh) == by_src->piece_len) p.piece_shift = sh;
-    p.run_prefix = run_prefix; p.row_list = row_list; p.list_offset = list_offset;
+    p.run_prefix = run_prefix; p.row_list = row_list; p.list_offset = list_offset; p.list_len = (int)row_list_len;
     p.slices = kFrontierLdsSlices;
     const size_t msg_bytes = (size_t)n_rel * kTile * sizeof(float);
     const int fgrid = (int)n_query * p.slices;
@@ -1762,6 +1765,7 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
     if (rc) return rc;
     // (3) the epilogue on the listed rows, in place
     cp.update = out; cp.out = out; cp.rows = n_dst * n_query; cp.row_list = row_list; cp.list_count = list_offset + n_query;
+    cp.list_len = (int)row_list_len;
     hipLaunchKernelGGL((combine_kernel<false, 3>), dim3((unsigned)(2 * di->n_cu)), dim3(kCbWaves * 64), lds_cb, s, cp);
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
