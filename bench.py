@@ -596,10 +596,12 @@ def pretrain_timing(dev, seed, rank, world, ranks, quick):
         with_comm, _, _ = loop(same, True)
         without, _, _ = loop(same, False)                            # LAST: the ranks' weights drift apart from here on
         mode = next(iter(graphed.steps.values())).mode
-        out.update({"gradient_allreduce": "engine.GradientReducer: %d buckets, %d fp32 parameters, %s, side stream; step mode `%s` "
-                                          "(phased: 3 captured phases, each phase's buckets all-reduced while the next phase "
-                                          "replays; after: one graph, buckets after the replay); + 1 packed metric all-reduce"
-                                          % (len(reducer.buckets), sum(b["numel"] for b in reducer.buckets), dist.get_backend(), mode),
+        out.update({"gradient_allreduce": "engine.GradientReducer: %d buckets in %d groups (one all-reduce per group), %d fp32 "
+                                          "parameters, %s, side stream; step mode `%s` (phased: 3 captured phases, each phase's group "
+                                          "all-reduced while the next phase replays; after: one graph, the groups after the replay); "
+                                          "+ 1 packed metric all-reduce"
+                                          % (len(reducer.buckets), len(reducer.groups), sum(b["numel"] for b in reducer.buckets),
+                                             dist.get_backend(), mode),
                     "step_mode": mode,
                     "same_graphs_step_ms_with_allreduce": 1e3 * with_comm / n_steps,
                     "same_graphs_step_ms_without_allreduce": 1e3 * without / n_steps,

@@ -136,7 +136,7 @@ def _worker(rank, world, port, out_dir):
     multi.train()
     opt_m = torch.optim.AdamW(multi.parameters(), lr=5e-4)
     reducer = engine.GradientReducer(multi, overlap=True)
-    assert reducer.warm() == len(reducer.buckets) and reducer.total_launched == len(reducer.buckets) and reducer.rounds == 0
+    assert reducer.warm() == len(reducer.groups) == 3 and reducer.total_launched == len(reducer.buckets) and reducer.rounds == 0
     hops = (["default", "second", "second", "default"], ["second", "second", "default", "default"])[rank]
     pools = {"default": triples, "second": torch.from_numpy(other)}
     with oracle_rspmm(0):
@@ -145,6 +145,7 @@ def _worker(rank, world, port, out_dir):
             multi._static_negative = torch.randint(0, 90, (8, 8), generator=torch.Generator().manual_seed(31 * s + rank))
             engine.train_step(multi, opt_m, (pools[gid][50 * s + 8 * rank: 50 * s + 8 * rank + 8], gid), reducer=reducer)
             assert reducer.total_launched - before == len(reducer.buckets) and reducer.rounds == s + 1
+            assert reducer.collectives == 3 * (s + 2)           # warm() + one all-reduce per GROUP and step
     multi._static_negative = None
     reducer.remove_hooks()
     hop_params = torch.cat([p.detach().reshape(-1) for p in multi.parameters()])

@@ -421,7 +421,8 @@ def test_gradient_reducer_over_rccl_single_rank_group():
         for i, graph in enumerate(step.graphs):
             graph.replay = (lambda real, i=i: lambda: (events.append(("replay", i)), real())[1])(graph.replay)
         real_group = reducer.launch_group
-        reducer.launch_group = lambda group: (events.append(("allreduce", tuple(group))), real_group(group))[1]
+        reducer.launch_group = lambda g: (events.append(("allreduce", tuple(reducer.groups[g]))), real_group(g))[1]
+        collectives = reducer.collectives
         losses_g, negs = [], []
         for b in batches:
             del events[:]
@@ -429,6 +430,8 @@ def test_gradient_reducer_over_rccl_single_rank_group():
             negs.append(step.last_negatives.clone())
             assert events == [("replay", 0), ("allreduce", tuple(step.groups[0])), ("replay", 1),
                               ("allreduce", tuple(step.groups[1])), ("replay", 2), ("allreduce", tuple(step.groups[2]))]
+            collectives += 3                             # ONE all-reduce per group: three per step, not one per bucket
+            assert reducer.collectives == collectives
             for p in twin.parameters():                 # the gradients the optimizer saw live in the reducer's flat buffers
                 if p.grad is not None:
                     assert any(p.grad.untyped_storage().data_ptr() == bk["flat"].untyped_storage().data_ptr()

@@ -237,33 +237,18 @@ class GraphedTrainStep:
 
     # ------------------------------------------------------------------ phased capture
     def _phases(self):
-        """Which phase of the backward completes each parameter's gradient -- 0: score head and the entity layers after the
-        cut; 1: the earlier entity layers, the grouped relation projections and anything else of the entity model; 2: the
-        relation models -- and, from that, the reducer's buckets per phase (contiguous runs in bucket order)."""
+        """Which phase of the backward completes each parameter's gradient -- the reducer's group of its bucket (0: score head
+        and the entity layers after the cut; 1: the earlier entity layers and the grouped relation projections; 2: the relation
+        models); parameters outside the buckets (they receive no gradient) are listed with the stack they belong to."""
         task, reducer = self.task, self.reducer
-        k = self.cut_after
+        if len(reducer.groups) != 3 or reducer.cut_after != self.cut_after:
+            raise _NoPhases("the reducer's groups (%d, cut after layer %s) do not match the three phases of this model"
+                            % (len(reducer.groups), reducer.cut_after))
         phase_of = {}
         for name, p in task.named_parameters():
-            parts = name.split(".")
-            if parts[0] == "rel_models":
-                phase = 2
-            elif name.startswith("model.mlp."):
-                phase = 0
-            elif (parts[0] == "model" and parts[1] == "layers" and "relation_projection" not in parts
-                  and parts[3] in ("linear", "layer_norm") and int(parts[2]) >= k):
-                phase = 0
-            else:
-                phase = 1
-            phase_of[id(p)] = phase
-        groups = [[], [], []]
-        last = 0
-        for b, bucket in enumerate(reducer.buckets):
-            phase = max(phase_of[id(p)] for p in bucket["params"])
-            if phase < last:
-                raise _NoPhases("bucket `%s` completes in phase %d after a bucket of phase %d" % (bucket["name"], phase, last))
-            last = phase
-            groups[phase].append(b)
-        return phase_of, groups
+            b = reducer._bucket_of.get(id(p))
+            phase_of[id(p)] = reducer._group_of[b] if b is not None else (2 if name.startswith("rel_models.") else 1)
+        return phase_of, reducer.groups
 
     def _capture_phased(self):
         task, model, reducer = self.task, self.task.model, self.reducer
@@ -323,10 +308,10 @@ class GraphedTrainStep:
 
     def _replay_phases(self, communicate):
         reducer = self.reducer
-        for graph, group in zip(self.graphs, self.groups):
+        for g, graph in enumerate(self.graphs):
             graph.replay()
             if communicate:
-                reducer.launch_group(group)         # side stream: RCCL works while the next phase replays
+                reducer.launch_group(g)             # side stream: RCCL works while the next phase replays
         if communicate:
             reducer.wait_groups()
 
@@ -697,20 +682,25 @@ class GradientReducer:
     """Bucketed gradient all-reduce that overlaps the backward pass (what DDP does for the reference,
     ``ultra/engine.py:55-60``; BASELINE north star: "overlapped with the next layer's rspmm on a side HIP stream").
 
-    Buckets follow the order in which backward produces gradients: the score head first, then the entity layers last to
+    BUCKETS follow the order in which backward produces gradients: the score head first, then the entity layers last to
     first (each layer's ``linear`` + ``layer_norm``: ready right after its rspmm backward), then ONE bucket with the relation
     projections of all entity layers (a single grouped autograd node that runs after the first layer's backward; round 3 kept
     them in their layers' buckets, so no entity bucket could leave before the whole entity stack was done), then the
-    relation-model layers last to first.  A ``post_accumulate_grad`` hook per parameter counts a bucket down; when
-    the last gradient of a bucket exists the bucket is packed on the compute stream into its PERSISTENT flat buffer
-    (allocated once: nothing is allocated or freed per step, so the same code is capturable into a hipGraph), and its
-    all-reduce is enqueued on a SIDE stream (RCCL runs it there while the compute stream continues with the next layer's
-    rspmm backward).  Buckets are always launched in bucket order, so every rank issues the same sequence of collectives
-    even when ranks train on different graphs (multi-graph pre-training, ``ultra/engine.py:23-34``).  ``finish()`` makes
-    the compute stream wait for the side stream and unpacks the averaged gradients; it must run before
-    ``optimizer.step()`` and after EVERY backward whose hooks were live (a backward without it leaves buckets in flight:
-    ``finish()`` refuses to start from such a state).  Parameters that never receive a gradient
-    (``UNUSED_PARAMETER_MARKS``) are excluded statically."""
+    relation-model layers last to first.  All buckets are slices of ONE persistent flat buffer (allocated once: nothing is
+    allocated or freed per step).  GROUPS are runs of consecutive buckets that complete in one phase of the backward -- (0) the
+    score head and the later half of the entity layers, (1) the earlier entity layers and the projections, (2) the relation
+    model -- and a group is the unit of communication: ONE all-reduce over the group's contiguous slice, enqueued on a SIDE
+    stream as soon as the group's last bucket is packed (RCCL runs it there while the compute stream continues with the next
+    layers' backward).  Three collectives per step instead of fourteen: on xGMI a 30-200 KB all-reduce is latency, not bandwidth
+    (the reference's DDP sends its 0.78 MB of gradients as one bucket).  Every path -- eager hooks, ``finish()`` after a paused
+    backward, the phased captured step -- sends the SAME groups in the same order, so ranks in different modes or on different
+    graphs (multi-graph pre-training, ``ultra/engine.py:23-34``) issue identical sequences of collectives.
+
+    A ``post_accumulate_grad`` hook per parameter counts a bucket down; complete buckets are packed on the compute stream in bucket
+    order (one ``cat`` kernel each).  ``finish()`` makes the compute stream wait for the side stream and unpacks the averaged
+    gradients; it must run before ``optimizer.step()`` and after EVERY backward whose hooks were live (a backward without it
+    leaves groups in flight: a second one is refused).  Parameters that never receive a gradient (``UNUSED_PARAMETER_MARKS``)
+    are excluded statically."""
 
     def __init__(self, module, average=True, overlap=True, single_rank=False):
         """``single_rank``: issue the collectives even in a one-rank group (a one-GPU box can then exercise the RCCL
@@ -733,24 +723,43 @@ class GradientReducer:
                 return (1 + 2 * stack, -int(parts[i + 1]), ".".join(parts[:i + 2]))
             return (0, 0, parts[0] + "." + parts[1] if len(parts) > 1 else parts[0])      # score head, query embeddings
 
-        groups = {}
+        by_key = {}
         for name, p in named:
-            groups.setdefault(bucket_key(name), []).append((name, p))
+            by_key.setdefault(bucket_key(name), []).append((name, p))
+        keys = sorted(by_key)
         self.buckets = []
-        for key in sorted(groups):
-            params = [p for _, p in groups[key]]
-            self.buckets.append({"name": key[2], "params": params, "names": [n for n, _ in groups[key]],
-                                 "numel": sum(p.numel() for p in params), "flat": None, "work": None})
+        for key in keys:
+            params = [p for _, p in by_key[key]]
+            self.buckets.append({"name": key[2], "params": params, "names": [n for n, _ in by_key[key]],
+                                 "numel": sum(p.numel() for p in params), "flat": None})
         self._bucket_of = {}
         for b, bucket in enumerate(self.buckets):
             for p in bucket["params"]:
                 self._bucket_of[id(p)] = b
+        # groups: where the phased backward is cut (GraphedTrainStep) -- after the entity layer model.cut_at() (the middle)
+        model = getattr(module, "model", None)
+        cut = model.cut_at() if hasattr(model, "cut_at") else None
+        if not isinstance(cut, int):
+            entity = [-key[1] for key in keys if key[0] == 1]
+            cut = (max(entity) + 1) // 2 if entity else 0
+        self.cut_after = cut
+        phases = [0 if key[0] == 0 else ((0 if -key[1] >= cut else 1) if key[0] == 1 else (1 if key[0] == 2 else 2)) for key in keys]
+        self.groups = []
+        for b, phase in enumerate(phases):              # (phases are non-decreasing in bucket order)
+            if not self.groups or phases[b - 1] != phase:
+                self.groups.append([])
+            self.groups[-1].append(b)
+        self._group_of = {b: g for g, group in enumerate(self.groups) for b in group}
+        self._flat_all = None
+        self._group_flat = [None] * len(self.groups)
+        self._work = [None] * len(self.groups)
         self._side = None
         self._handles = []
         self._paused = False
-        self.launched_from_hooks = 0            # buckets whose all-reduce a hook started (i.e. during backward), last step
-        self.total_launched = 0                 # bucket all-reduces issued since construction (gradient rounds + warm())
-        self.rounds = 0                         # completed finish() rounds that carried gradients
+        self.launched_from_hooks = 0            # buckets packed (and their groups sent) from hooks, i.e. during backward, last step
+        self.total_launched = 0                 # buckets whose reduction was issued since construction (gradient rounds + warm())
+        self.collectives = 0                    # all-reduce calls issued since construction
+        self.rounds = 0                         # completed rounds that carried gradients
         self._reset()
         if overlap:
             for bucket in self.buckets:
@@ -760,7 +769,7 @@ class GradientReducer:
     def _reset(self):
         self._pending = [len(b["params"]) for b in self.buckets]
         self._ready = [False] * len(self.buckets)
-        self._next = 0
+        self._next = 0                          # next bucket to pack / send
         self._launched = 0
         self._from_hooks = 0
 
@@ -784,15 +793,84 @@ class GradientReducer:
         return ctx()
 
     def abandon(self):
-        """Forget buckets in flight (after a failed capture: their work handles belong to a dead graph)."""
-        for bucket in self.buckets:
-            bucket["work"] = None
+        """Forget groups in flight (after a failed capture: their work handles belong to a dead graph)."""
+        self._work = [None] * len(self.groups)
         self._reset()
 
-    # ------------------------------------------------------------------ hooks (autograd thread, during backward)
     def _active(self):
         return dist.is_initialized() and (get_world_size() > 1 or self.single_rank)
 
+    def _op(self):
+        """Averaging inside the collective where the backend has it (RCCL: no division kernel per group); gloo sums."""
+        if self.average and get_world_size() > 1 and dist.get_backend() == "nccl":
+            return dist.ReduceOp.AVG, False
+        return dist.ReduceOp.SUM, self.average and get_world_size() > 1
+
+    # ------------------------------------------------------------------ buffers
+    def flat_buffers(self, device):
+        """The persistent flat buffer (allocated on first use, never per step): one slice per bucket, one per group."""
+        if self._flat_all is None or self._flat_all.device != device:
+            self._flat_all = torch.zeros(sum(b["numel"] for b in self.buckets), dtype=torch.float32, device=device)
+            offset = 0
+            for g, group in enumerate(self.groups):
+                first = offset
+                for b in group:
+                    self.buckets[b]["flat"] = self._flat_all[offset:offset + self.buckets[b]["numel"]]
+                    offset += self.buckets[b]["numel"]
+                self._group_flat[g] = self._flat_all[first:offset]
+        return [bucket["flat"] for bucket in self.buckets]
+
+    def views(self):
+        """``{id(param): view of its slice of the flat buffer}``: a step that packs its gradients into the flat buffer binds
+        these as ``param.grad`` -- the all-reduce then happens in place under the optimizer's feet and nothing is unpacked."""
+        out = {}
+        for bucket in self.buckets:
+            offset = 0
+            for p in bucket["params"]:
+                out[id(p)] = bucket["flat"][offset:offset + p.numel()].view_as(p)
+                offset += p.numel()
+        return out
+
+    def pack(self, b, grads):
+        """Bucket ``b``'s gradients (``{id(param): tensor}``; a parameter without one counts as zeros) into its slice of the flat
+        buffer: ONE kernel on the current stream (``cat``; ``copy_()`` of same-dtype tensors would be a device-to-device memcpy,
+        i.e. a memcpy NODE under hipGraph capture: kernels only, see DESIGN.md on memset nodes), capturable."""
+        bucket = self.buckets[b]
+        torch.cat([(grads[id(p)] if grads.get(id(p)) is not None else torch.zeros_like(p)).reshape(-1)
+                   for p in bucket["params"]], out=bucket["flat"])
+
+    def _send(self, g):
+        """The all-reduce of group ``g`` (already packed): on the side stream, behind everything the compute stream has been
+        given so far."""
+        flat = self._group_flat[g]
+        op = self._op()[0]
+        if flat.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=flat.device)
+            self._side.wait_stream(torch.cuda.current_stream(flat.device))   # the packs must be complete
+            with torch.cuda.stream(self._side):
+                self._work[g] = dist.all_reduce(flat, op=op, async_op=True)  # RCCL, enqueued behind the side stream
+        else:
+            self._work[g] = dist.all_reduce(flat, op=op, async_op=True)
+        self.collectives += 1
+
+    def warm(self):
+        """One explicit all-reduce per group, in order, on the side stream: initialises RCCL's channels and allocates the
+        persistent flat buffer outside any captured or timed step.  A collective like any other: every rank must call it at
+        the same point (the constructors of the graphed steps do).  Gradients are not touched.  Returns the number of
+        collectives issued."""
+        if not self._active():
+            return 0
+        self.flat_buffers(next(p.device for b in self.buckets for p in b["params"]))
+        for g, group in enumerate(self.groups):
+            self._send(g)
+            self.total_launched += len(group)
+        for g in range(len(self.groups)):
+            self._work[g].wait()
+            self._work[g] = None
+        return len(self.groups)
+
+    # ------------------------------------------------------------------ hooks (autograd thread, during backward)
     def _on_grad(self, param):
         if self._paused or not self._active():
             return
@@ -805,159 +883,82 @@ class GradientReducer:
             self._ready[b] = True
             while self._next < len(self.buckets) and self._ready[self._next]:
                 self._launch(self._next)
-                self._next += 1
                 self._from_hooks += 1
 
     def _launch(self, b):
+        """Pack bucket ``b`` from the parameters' ``.grad`` (always in bucket order) and, when it completes its group, send
+        the group."""
+        if b != self._next:
+            raise RuntimeError("GradientReducer: bucket %d packed out of order (next is %d)" % (b, self._next))
         bucket = self.buckets[b]
-        params = bucket["params"]
-        ref = next((p.grad for p in params if p.grad is not None), params[0])
-        flat = bucket["flat"]
-        if flat is None or flat.device != ref.device:
-            flat = bucket["flat"] = torch.empty(bucket["numel"], dtype=torch.float32, device=ref.device)
-        # packed on the compute stream by ONE kernel (cat; copy_() of same-dtype tensors would be a device-to-device
-        # memcpy, i.e. a memcpy NODE under hipGraph capture: kernels only, see DESIGN.md on memset nodes)
-        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params], out=flat)
-        if flat.is_cuda:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=flat.device)
-            self._side.wait_stream(torch.cuda.current_stream(flat.device))   # the pack must be complete
-            with torch.cuda.stream(self._side):
-                bucket["work"] = dist.all_reduce(flat, op=self._op()[0], async_op=True)     # RCCL, enqueued behind the side stream
-        else:
-            bucket["work"] = dist.all_reduce(flat, op=self._op()[0], async_op=True)
+        ref = next((p.grad for p in bucket["params"] if p.grad is not None), bucket["params"][0])
+        self.flat_buffers(ref.device)
+        self.pack(b, {id(p): p.grad for p in bucket["params"]})
+        self._next += 1
         self._launched += 1
         self.total_launched += 1
-
-    def warm(self):
-        """One explicit all-reduce per bucket, in bucket order, on the side stream: initialises RCCL's channels and
-        allocates the persistent flat buffers outside any captured or timed step.  A collective like any other: every
-        rank must call it at the same point (the constructors of the graphed steps do).  Gradients are not touched."""
-        if not self._active():
-            return 0
-        device = next(p.device for b in self.buckets for p in b["params"])
-        works = []
-        for bucket in self.buckets:
-            if bucket["flat"] is None or bucket["flat"].device != device:
-                bucket["flat"] = torch.zeros(bucket["numel"], dtype=torch.float32, device=device)
-            flat = bucket["flat"]
-            if flat.is_cuda:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=device)
-                self._side.wait_stream(torch.cuda.current_stream(device))
-                with torch.cuda.stream(self._side):
-                    works.append(dist.all_reduce(flat, async_op=True))
-            else:
-                works.append(dist.all_reduce(flat, async_op=True))
-            self.total_launched += 1
-        for work in works:
-            work.wait()
-        return len(works)
+        g = self._group_of[b]
+        if b == self.groups[g][-1]:
+            self._send(g)
 
     # ------------------------------------------------------------------ phased steps (engine.GraphedTrainStep)
-    def _op(self):
-        """Averaging inside the collective where the backend has it (RCCL: no division kernel per bucket); gloo sums."""
-        if self.average and get_world_size() > 1 and dist.get_backend() == "nccl":
-            return dist.ReduceOp.AVG, False
-        return dist.ReduceOp.SUM, self.average and get_world_size() > 1
-
-    def flat_buffers(self, device):
-        """The persistent flat buffer of every bucket (allocated on first use, never per step)."""
-        for bucket in self.buckets:
-            if bucket["flat"] is None or bucket["flat"].device != device:
-                bucket["flat"] = torch.zeros(bucket["numel"], dtype=torch.float32, device=device)
-        return [bucket["flat"] for bucket in self.buckets]
-
-    def views(self):
-        """``{id(param): view of its slice of the bucket's flat buffer}``: a step that packs its gradients into the flat
-        buffers binds these as ``param.grad`` -- the all-reduce then happens in place under the optimizer's feet and nothing
-        is unpacked."""
-        out = {}
-        for bucket in self.buckets:
-            offset = 0
-            for p in bucket["params"]:
-                out[id(p)] = bucket["flat"][offset:offset + p.numel()].view_as(p)
-                offset += p.numel()
-        return out
-
-    def pack(self, b, grads):
-        """Bucket ``b``'s gradients (``{id(param): tensor}``; a parameter without one counts as zeros) into its flat buffer:
-        ONE kernel on the current stream, capturable into a hipGraph (a kernel node; no collective is captured)."""
-        bucket = self.buckets[b]
-        torch.cat([(grads[id(p)] if grads.get(id(p)) is not None else torch.zeros_like(p)).reshape(-1)
-                   for p in bucket["params"]], out=bucket["flat"])
-
-    def launch_group(self, group):
-        """All-reduce the (already packed) buckets ``group`` -- ascending bucket indices, continuing where the previous group
-        ended -- on the side stream, behind everything the compute stream has been given so far; the compute stream goes on
-        (the next phase's replay) while RCCL works.  :meth:`wait_groups` ends the round."""
+    def launch_group(self, g):
+        """All-reduce group ``g``, whose buckets the caller has packed (:meth:`pack`, e.g. as the last kernels of a captured
+        phase): the groups go out in order; the compute stream goes on (the next phase's replay) while RCCL works.
+        :meth:`wait_groups` ends the round."""
         if not self._active():
             return
-        op, divide = self._op()
-        first = None
-        for b in group:
-            if b != self._next:
-                raise RuntimeError("GradientReducer: bucket %d launched out of order (next is %d): every rank must issue "
-                                   "the buckets in the same order" % (b, self._next))
-            flat = self.buckets[b]["flat"]
-            if flat.is_cuda:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=flat.device)
-                if first is None:
-                    self._side.wait_stream(torch.cuda.current_stream(flat.device))
-                    first = b
-                with torch.cuda.stream(self._side):
-                    self.buckets[b]["work"] = dist.all_reduce(flat, op=op, async_op=True)
-            else:
-                self.buckets[b]["work"] = dist.all_reduce(flat, op=op, async_op=True)
-            self._next += 1
-            self._launched += 1
-            self.total_launched += 1
+        group = self.groups[g]
+        if group[0] != self._next:
+            raise RuntimeError("GradientReducer: group %d sent out of order (next bucket is %d): every rank must issue the "
+                               "groups in the same order" % (g, self._next))
+        self._send(g)
+        self._next = group[-1] + 1
+        self._launched += len(group)
+        self.total_launched += len(group)
+
+    def _wait_all(self):
+        divide = self._op()[1]
+        for g in range(len(self.groups)):
+            self._work[g].wait()                    # the current stream (or the host, gloo) waits for this collective
+            if divide:                              # (gloo only: RCCL averages inside the collective)
+                self._group_flat[g].div_(get_world_size())
+            self._work[g] = None
 
     def wait_groups(self):
-        """The compute stream waits for every bucket launched by :meth:`launch_group`; the flat buffers then hold the
-        averaged gradients (bound as ``param.grad`` through :meth:`views`).  All buckets must have been launched."""
+        """The compute stream waits for every group sent by :meth:`launch_group`; the flat buffer then holds the averaged
+        gradients (bound as ``param.grad`` through :meth:`views`).  All groups must have been sent."""
         if not self._active():
             self._reset()
             return
         if self._next != len(self.buckets):
-            raise RuntimeError("GradientReducer: %d of %d buckets were launched in this round" % (self._next, len(self.buckets)))
-        op, divide = self._op()
-        for bucket in self.buckets:
-            bucket["work"].wait()                   # the current stream (or the host, gloo) waits for this collective
-            if divide:                              # (gloo only: RCCL averages inside the collective)
-                bucket["flat"].div_(get_world_size())
-            bucket["work"] = None
+            raise RuntimeError("GradientReducer: %d of %d buckets were sent in this round" % (self._next, len(self.buckets)))
+        self._wait_all()
         self.rounds += 1
         self._reset()
 
     # ------------------------------------------------------------------ after backward, before optimizer.step()
     def finish(self):
-        """Wait for every bucket (launching those whose hooks did not fire: ``overlap=False``, ``paused()`` or a graph
+        """Wait for every group (packing and sending those the hooks did not: ``overlap=False``, ``paused()`` or a graph
         replay) and write the reduced gradients back.  Returns the number of fp32 elements reduced."""
-        world = get_world_size()
         if not self._active():
             self._reset()
             return 0
         while self._next < len(self.buckets):                               # in bucket order, on every rank
             self._launch(self._next)
-            self._next += 1
+        self._wait_all()
         total = 0
         for bucket in self.buckets:
-            bucket["work"].wait()                                           # compute stream waits for the collective
             flat = bucket["flat"]
-            if self._op()[1]:
-                flat /= world
             offset = 0
             for p in bucket["params"]:
                 n = p.numel()
                 if p.grad is None:
                     p.grad = flat[offset:offset + n].view_as(p).clone()
-                else:                                                       # an elementwise kernel, not a memcpy (see _launch)
+                else:                                                       # an elementwise kernel, not a memcpy (see pack)
                     torch.mul(flat[offset:offset + n].view_as(p.grad), 1.0, out=p.grad)
                 offset += n
             total += flat.numel()
-            bucket["work"] = None
         self.launched_from_hooks = self._from_hooks
         self.rounds += 1
         self._reset()
