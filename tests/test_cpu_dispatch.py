@@ -7,6 +7,7 @@ forward and both gradients, with and without edge weights, ragged widths and emp
 equal to the oracle's coalesce; and config 1 end to end -- inductive zero-shot ``predict`` of the shipped architecture
 on CPU tensors with no backend installed, against the same model with the oracle behind the operator.
 """
+import os
 import zlib
 
 import numpy as np
@@ -341,3 +342,41 @@ def test_cpu_path_equals_the_aten_definition_of_the_reference():
         s = g_true[k].abs().max().item() + 1e-12
         e, e_aten = (g[k] - g_true[k]).abs().max().item(), (g_aten[k] - g_true[k]).abs().max().item()
         assert e <= 4 * e_aten + 1e-4 * s, (k, e, e_aten, s)
+
+
+def test_cpu_forward_kernel_gives_the_same_bits_on_every_isa_level():
+    """The CPU forward kernel is compiled three times (baseline x86-64, AVX2, AVX-512: the library is built once and travels
+    to other hosts) and picks a level at run time; ``ULTRA_CPU_ISA`` caps it.  Every level this host supports must give the
+    SAME bytes for all six operator pairs (element-wise vector code in the row's edge order, no FMA, no reassociation) --
+    checked in one child process per level against this process's result, which the other tests hold to the oracle."""
+    import hashlib
+    import subprocess
+    import sys
+    script = r"""
+import hashlib, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from ultra_torchdrug_amd import _torch_ext
+ops = _torch_ext.load()
+rng = np.random.default_rng(12)
+n, r, e, F = 300, 7, 5000, 328            # 328 = 256 + 64 + 8: a full AVX-512 slab, a full AVX2 slab and a ragged tail
+dst = np.sort(rng.integers(0, n, e)); src = rng.integers(0, n, e); rel = rng.integers(0, r, e)
+row_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]).astype(np.int32))
+src_t, rel_t = torch.from_numpy(src.astype(np.int32)), torch.from_numpy(rel.astype(np.int32))
+w = torch.from_numpy(rng.uniform(0.25, 2.0, e).astype(np.float32))
+relation = torch.from_numpy(rng.standard_normal((r, F)).astype(np.float32))
+x = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32))
+h = hashlib.sha256()
+for s in range(3):
+    for m in range(2):
+        for weight in (None, w):
+            h.update(ops.rspmm_fwd(row_ptr, src_t, rel_t, weight, relation, x, s, m).numpy().tobytes())
+print("DIGEST", h.hexdigest())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for level in ("0", "1", "2"):
+        run = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, ULTRA_CPU_ISA=level, OMP_NUM_THREADS="2"))
+        lines = [line for line in run.stdout.splitlines() if line.startswith("DIGEST")]
+        assert run.returncode == 0 and lines, run.stderr[-1500:]
+        digests[level] = lines[-1].split()[1]
+    assert len(set(digests.values())) == 1, digests
