@@ -92,23 +92,31 @@ class GraphedPredict:
     (``ultra/model.py:174-175``) are host syncs and cannot be captured; ``predict`` builds those index grids
     itself (``ultra/task.py:249-259``) so they hold by construction and are switched off for the capture."""
 
-    def __init__(self, task, example_batch, warmup=3):
+    def __init__(self, task, example_batch, warmup=3, with_ranks=False):
+        """``with_ranks``: the filtered ranking of the batch (``task.rank_batch``: two key-search kernels, no host
+        synchronisation) is captured behind ``predict`` in the same graph; :meth:`ranks` then replays both."""
         assert example_batch.is_cuda and not task.training
         self.task = task
         self.static_batch = validate_triples(task, example_batch).clone()
+        self.static_ranks = None
         model = task.model
         model.check_indices = False
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
+                pred = None
                 for _ in range(warmup):             # builds plans, sets kernel attributes, warms the allocator
-                    task.predict(self.static_batch)
+                    pred = task.predict(self.static_batch)
+                if with_ranks:                      # ... and the completion keys the rank kernels search
+                    task.rank_batch(self.static_batch, pred=pred)
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: other threads of the process (the RCCL watchdog polls events) must not abort the capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
                 self.static_pred = task.predict(self.static_batch)
+                if with_ranks:
+                    self.static_ranks = task.rank_batch(self.static_batch, pred=self.static_pred)
         finally:
             model.check_indices = True
 
@@ -120,6 +128,15 @@ class GraphedPredict:
         self.static_batch.copy_(batch)
         self.graph.replay()
         return self.static_pred
+
+    def ranks(self, batch):
+        """Filtered ranks ``(B, 2)`` int64 of ``batch`` (``with_ranks=True``); a fresh tensor."""
+        if self.static_ranks is None or batch.shape != self.static_batch.shape:
+            with torch.no_grad():
+                return self.task.rank_batch(batch)
+        self.static_batch.copy_(batch)
+        self.graph.replay()
+        return self.static_ranks.clone()
 
 
 class GraphedTrainStep:
@@ -595,12 +612,12 @@ def evaluate(task, triples, batch_size=16, graphed=None, cache_relations=None, u
     try:
         ranks = _ranks_of_unique_queries(task, local, batch_size, graphed) if unique_queries and len(local) else None
         if ranks is None:
-            replay = GraphedPredict(task, local[:batch_size]) if graphed and len(local) >= batch_size else None
+            # predict AND the filtered ranking of a batch as one replay (only the (B, 2) ranks are copied out per batch)
+            replay = GraphedPredict(task, local[:batch_size], with_ranks=True) if graphed and len(local) >= batch_size else None
             ranks = []
             for i in range(0, len(local), batch_size):
                 batch = local[i:i + batch_size]
-                pred = replay(batch) if replay is not None and len(batch) == batch_size else None
-                ranks.append(task.rank_batch(batch, pred=pred))
+                ranks.append(replay.ranks(batch) if replay is not None else task.rank_batch(batch))
             ranks = torch.cat(ranks) if ranks else torch.zeros(0, 2, dtype=torch.long, device=device)
     finally:
         if cache_relations:
