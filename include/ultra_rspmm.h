@@ -37,8 +37,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared here are exported
+ * (tests/test_host_logic.py compares `nm -D` of the built library with this header). */
+#pragma GCC visibility push(default)
 
-#define ULTRA_RSPMM_ABI_VERSION 6
+#define ULTRA_RSPMM_ABI_VERSION 7
 
 /* sum= / mul= of generalized_rspmm (layer.py:134-167: sum in {"add","max","min"}, mul in {"mul","add"}) */
 enum ultra_sum_op { ULTRA_SUM_ADD = 0, ULTRA_SUM_MIN = 1, ULTRA_SUM_MAX = 2 };
@@ -83,6 +86,13 @@ typedef struct ultra_segments {
     /* optional row pointers [n_rows + 1] (first edge of every target row); with them, plans of big graphs (node ids  */
     /* outside the packed word) that have no split rows run one row per 16-lane group (csrc/rowgroup.inc)           */
     const int32_t *row_ptr;
+    /* optional DENSE form (ABI 7; ultra_relcsr_dense): the plan's edges as a 0/1 byte matrix, for unit-weight plans over  */
+    /* exactly 4 relation types -- the relation graphs of /root/reference/ultra/rel_model.py:99-143, which multiply       */
+    /* incidence matrices and come out dense (the FB15k237-shaped one is complete: 474 x 474 x 4).  With it the sum        */
+    /* aggregations run on the exact-f32 matrix cores (csrc/relgraph_dense.hip); NULL = walk the edge list.                */
+    const uint32_t *dense;
+    int64_t dense_rows;        /* nodes along the matrix's 16-row tiles (forward: n_dst, d_input: n_src, d_relation: n_dst) */
+    int64_t dense_cols;        /* gathered nodes (forward: n_src, d_input: n_dst, d_relation: n_src)                        */
 } ultra_segments;
 
 int ultra_rspmm_abi_version(void);
@@ -110,7 +120,7 @@ int ultra_rspmm_event_elapsed_ms(void *start_event, void *stop_event, float *ms_
  * chunks per wave (quad_kernel) would run, bit 3 the chunked kernels where one row per 16-lane group (rowgroup_kernel)
  * would run, bit 4 the wide-group forms of that kernel (32 / 64 lanes per row, column tiles of 128 / 256) on inputs small
  * enough to be cache-resident, bit 5 makes quad_kernel walk a label's column tiles one after the other where it would
- * work on several at once (small graphs).  Bit 0 also selects the L2-row form of the first-layer frontier kernel where the
+ * work on several at once (small graphs), bit 6 walks the edge list of a plan that carries a dense form.  Bit 0 also selects the L2-row form of the first-layer frontier kernel where the
  * LDS-message form would run.  All paths return identical bits. */
 int ultra_rspmm_force_general_path(int on);
 
@@ -540,6 +550,46 @@ int ultra_relcsr_plan(const int32_t *row, const int32_t *node_a, const int32_t *
                       int64_t cap_chunks, int32_t *long_rows, int64_t cap_long, int32_t *packed,
                       int64_t packed_slack, int64_t *counts_host, void *temp, size_t temp_bytes, void *stream);
 
+/*
+ * Dense form of a plan (ABI 7).  construct_relation_graph (/root/reference/ultra/rel_model.py:99-143) builds the graph of
+ * relations from products of incidence matrices: 2R nodes, 4 edge types, unit weights, and dense by nature.  For such a
+ * plan the sum aggregation is a matrix product with a 0/1 matrix, and v_mfma_f32_16x16x4_f32 computes
+ *     acc = fmaf(a0, b0, acc); acc = fmaf(a1, b1, acc); acc = fmaf(a2, b2, acc); acc = fmaf(a3, b3, acc)
+ * (sequential, every step rounded like fmaf: tools/ubench/mfma_order.hip).  With a_k in {0, 1} and b_k = the ROUNDED message
+ * relation[k] (*|+) input[u] of edge type k, one instruction per gathered node u adds that node's (up to) four messages in
+ * relation order -- fmaf(1, y, acc) = acc + y, fmaf(0, y, acc) = acc for finite y -- so a row's sum is the strictly sequential
+ * (node, relation) sum of the reference for EVERY row: no pieces, no fix-up pass.
+ *   kind 0 (forward / d_input plan: rows are nodes):  byte [tile][col / 4][type][i][col % 4]                  = 1 iff edge (row 16 tile + i, node_a col, type)
+ *   kind 1 (d_relation plan: rows are the 4 types):   byte [type][tile][col / 16][col % 4][i][(col / 4) % 4] = 1 iff edge (node_b 16 tile + i, node_a col, type)
+ * (one byte per entry, the four entries a lane needs for consecutive MFMAs in one 32-bit word; columns padded to whole rounds of
+ * the kernels' register sets + a few hundred bytes the kernels may read past the end.)
+ * d_relation in this form has its own documented order (the reference's is a sum over all (dst, src) pairs of one type):
+ *     S[v][t] = sequential sum over sources u ascending of input[u] where edge (u -> v, t) exists   (exact adds)
+ *     tile sum T[tile][t] = ((q0 + q1) + q2) + q3,  q_k = ((P[4k] + P[4k+1]) + P[4k+2]) + P[4k+3],  P[j] = grad[16 tile + j] * S[16 tile + j][t]
+ *     d_relation[t] = sequential sum over tiles ascending of T[tile][t]
+ * (oracle/rspmm_oracle.c restates it; within rounding of the reference order, tests/test_relgraph_dense_gpu.py).
+ * Preconditions checked at dispatch, otherwise the edge list is walked: weight == NULL, n_rel == 4, sum = add, F % 16 == 0
+ * (d_relation: mul = mul and a workspace of ultra_rspmm_workspace_bytes()).  Inputs must be finite for exact equivalence
+ * (0 * inf = NaN where the edge list would skip a missing edge).
+ * ultra_relcsr_dense_bytes: size of the matrix (0 when the shape is not supported);  ultra_relcsr_dense: fill it from the
+ * plan's edge arrays (zero fill + one byte store per edge; the caller then sets plan->dense / dense_rows / dense_cols).
+ */
+size_t ultra_relcsr_dense_bytes(int64_t n_rows, int64_t n_cols, int kind);
+int ultra_relcsr_dense(const ultra_segments *plan, int64_t n_rows, int64_t n_cols, int kind, uint32_t *dense, void *stream);
+
+/*
+ * On-box calibration for the HBM roofline line of bench.py ("confirm on the box with a copy / gather
+ * calibration, report both"): the bare gather of `n_index` random 256-byte rows of `table` (n_rows x 64 fp32) -- four rows
+ * per wave-instruction (buffer_load_dwordx4), eight instructions in flight per wave, every lane's values summed into
+ * out[n_waves * 64] so that nothing is dropped -- i.e. the rowgroup kernel's access pattern with the relation operand, the
+ * row pointers, the reduction structure and the output rows taken away.  `*n_waves_host` receives the number of waves
+ * (out must hold 64 floats per wave; query it with out == NULL).  index values must be < n_rows; n_index is rounded down to
+ * a multiple of 2 048 per wave.
+ */
+int ultra_calibrate_gather_f32(const float *table, int64_t n_rows, const int32_t *index, int64_t n_index, float *out,
+                               int64_t *n_waves_host, void *stream);
+
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -149,7 +149,9 @@ def rspmm_forward(csr, relation, x, sum="add", mul="mul", piece=0):
     return out
 
 
-def rspmm_backward(csr, relation, x, out, grad, sum="add", mul="mul", piece=0, need_weight_grad=False):
+def rspmm_backward(csr, relation, x, out, grad, sum="add", mul="mul", piece=0, need_weight_grad=False, dense_relation=False):
+    """``dense_relation``: d_relation in the documented order of the HIP library's dense relation-graph form
+    (``oracle_rspmm_drelation_dense``: 4 relation types, unit weights, sum of DistMult messages) instead of ``piece``'s."""
     relation = np.ascontiguousarray(relation, dtype=np.float32)
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.ascontiguousarray(out, dtype=np.float32)
@@ -164,6 +166,12 @@ def rspmm_backward(csr, relation, x, out, grad, sum="add", mul="mul", piece=0, n
                                      MUL_OPS[mul], _i64(piece))
     if rc:
         raise RuntimeError("oracle_rspmm_backward failed: %d" % rc)
+    if dense_relation:
+        assert csr.n_rel == 4 and sum == "add" and mul == "mul" and bool(np.all(csr.w == 1.0))
+        rc = lib().oracle_rspmm_drelation_dense(_p(csr.row_ptr), _p(csr.col), _p(csr.rel), _p(x), _p(grad), _p(d_rel),
+                                                _i64(csr.n_rows), _i64(F))
+        if rc:
+            raise RuntimeError("oracle_rspmm_drelation_dense failed: %d" % rc)
     return (d_rel, d_x, d_w) if need_weight_grad else (d_rel, d_x)
 
 

@@ -43,6 +43,8 @@
  *   the same with piece  > 0 ......................... the HIP KERNELS' split-row order: equality with it shows the
  *       kernels do what DESIGN.md says, not that they match the reference; the evidence for that is the tolerance
  *       check against piece == 0 and the ATen restatement tests (tests/test_reference_definition_gpu.py);
+ *   oracle_rspmm_drelation_dense ..................... the HIP KERNELS' order of d_relation on a dense relation graph (round 5);
+ *       the forward and d_input of such a graph run in the REFERENCE order (piece == 0) on the matrix cores;
  *   oracle_combine_forward, oracle_linear_forward ..... the HIP KERNELS' fmaf order (ATen's order is unspecified);
  *       bit-equality there is by construction, the independent check is the tolerance test against torch;
  *   oracle_filtered_rank ............................. the reference's formula (task.py:307-315), integer work.
@@ -337,6 +339,48 @@ int oracle_rspmm_backward(const int32_t *row_ptr, const int32_t *col, const int3
         }
     }
     free(row_of);
+    return 0;
+}
+
+/*
+ * d_relation of a DENSE relation graph, in the HIP library's documented order (include/ultra_rspmm.h, "Dense form of a
+ * plan"; csrc/relgraph_dense.hip) -- the KERNEL's order, not the reference's: equality with it shows the kernel does what the
+ * header says; the evidence that it matches the reference is the tolerance check against oracle_rspmm_backward(piece = 0).
+ * Sum aggregation of DistMult messages, unit weights, exactly 4 relation types (rel_model.py:99-143):
+ *     S[v][t]  = sequential sum over the row's edges of type t, sources ascending, of x[u]        (starts at +0)
+ *     P[v][t]  = g[v] * S[v][t]                    (rows past the end of the last 16-row tile count as g = 0, S = 0)
+ *     q_k      = ((P[16 T + 4k] + P[16 T + 4k + 1]) + P[16 T + 4k + 2]) + P[16 T + 4k + 3]
+ *     tile[T]  = ((q_0 + q_1) + q_2) + q_3
+ *     d_relation[t] = sequential sum over tiles T ascending of tile[T]                              (starts at +0)
+ */
+int oracle_rspmm_drelation_dense(const int32_t *row_ptr, const int32_t *col, const int32_t *rel, const float *x,
+                                 const float *g, float *d_relation, int64_t n_rows, int64_t F) {
+    const int64_t n_tiles = (n_rows + 15) / 16;
+#pragma omp parallel for schedule(static)
+    for (int64_t f = 0; f < F; ++f) {
+        for (int t = 0; t < 4; ++t) {
+            float d = 0.0f;
+            for (int64_t T = 0; T < n_tiles; ++T) {
+                float q[4];
+                for (int k = 0; k < 4; ++k) {
+                    float P[4];
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t v = 16 * T + 4 * k + r;
+                        float S = 0.0f, gv = 0.0f;
+                        if (v < n_rows) {
+                            gv = g[v * F + f];
+                            for (int64_t e = row_ptr[v]; e < row_ptr[v + 1]; ++e)
+                                if (rel[e] == t) S = S + x[(int64_t)col[e] * F + f];
+                        }
+                        P[r] = gv * S;
+                    }
+                    q[k] = ((P[0] + P[1]) + P[2]) + P[3];
+                }
+                d = d + (((q[0] + q[1]) + q[2]) + q[3]);
+            }
+            d_relation[(int64_t)t * F + f] = d;
+        }
+    }
     return 0;
 }
 

@@ -15,9 +15,9 @@ from oracle import oracle as O
 class _OracleRSPMM(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, relation, input, csr_o, sum, mul, piece):
+    def forward(ctx, relation, input, csr_o, sum, mul, piece, dense_relation=False):
         out = O.rspmm_forward(csr_o, relation.detach().numpy(), input.detach().numpy(), sum, mul, piece=piece)
-        ctx.csr_o, ctx.sum, ctx.mul, ctx.piece = csr_o, sum, mul, piece
+        ctx.csr_o, ctx.sum, ctx.mul, ctx.piece, ctx.dense_relation = csr_o, sum, mul, piece, dense_relation
         out = torch.from_numpy(out)
         ctx.save_for_backward(relation, input, out)
         return out
@@ -26,8 +26,9 @@ class _OracleRSPMM(torch.autograd.Function):
     def backward(ctx, grad):
         relation, input, out = ctx.saved_tensors
         d_rel, d_x = O.rspmm_backward(ctx.csr_o, relation.detach().numpy(), input.detach().numpy(), out.numpy(),
-                                      grad.contiguous().numpy(), ctx.sum, ctx.mul, piece=ctx.piece)
-        return torch.from_numpy(d_rel), torch.from_numpy(d_x), None, None, None, None
+                                      grad.contiguous().numpy(), ctx.sum, ctx.mul, piece=ctx.piece,
+                                      dense_relation=ctx.dense_relation)
+        return torch.from_numpy(d_rel), torch.from_numpy(d_x), None, None, None, None, None
 
 
 class OracleFunctional:
@@ -127,8 +128,10 @@ class OracleFunctional:
         return torch.stack([flat.norm(), flat.mean(), flat.std()])
 
     def generalized_rspmm(self, sparse, relation, input, sum="add", mul="mul"):
-        piece = sparse.piece_len if self.piece is None else self.piece       # None: each plan's own piece length
-        return _OracleRSPMM.apply(relation.contiguous(), input.contiguous(), self._csr(sparse), sum, mul, piece)
+        # None: the order the library uses for this adjacency and call (each plan's own piece length; the reference order and
+        # the documented d_relation order where the plans carry their dense form)
+        piece, dense_relation = sparse.kernel_order(sum, mul, input.shape[1]) if self.piece is None else (self.piece, False)
+        return _OracleRSPMM.apply(relation.contiguous(), input.contiguous(), self._csr(sparse), sum, mul, piece, dense_relation)
 
     @staticmethod
     def _dense_boundary(boundary, n_rows):

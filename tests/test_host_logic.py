@@ -31,7 +31,62 @@ def test_library_exports_every_declared_symbol():
     assert lib.ultra_rspmm_abi_version() == version == _lib.ABI_VERSION
     assert lib.ultra_rspmm_status_string(1).decode().startswith("unknown sum/mul")
     import ctypes
-    assert ctypes.sizeof(_lib.UltraSegments) == 18 * 8          # struct layout of the header
+    assert ctypes.sizeof(_lib.UltraSegments) == 21 * 8          # struct layout of the header (ABI 7: + dense, dense_rows, dense_cols)
+
+
+def test_library_exports_nothing_but_the_header():
+    """`nm -D` of the built library == the functions include/ultra_rspmm.h declares (a thread_local and two
+    kernel handles leaked out).  -fvisibility=hidden + the header's visibility pragma; `__hip_cuid_*` are the HIP
+    toolchain's per-translation-unit markers, not ours to hide."""
+    import subprocess
+    from ultra_torchdrug_amd import _lib
+    header = open(os.path.join(ROOT, "include", "ultra_rspmm.h")).read()
+    declared = set(re.findall(r"^(?:int|size_t|const char \*)\s*(ultra_\w+)\s*\(", header, flags=re.M))
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    exported = {name for name in exported if not name.startswith("__hip_cuid_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+
+
+def test_dense_form_decision_and_sizes_match_the_library():
+    """relcsr.dense_bytes restates ultra_relcsr_dense_bytes (the decision must be the same for a CPU copy of a graph: it tells
+    the oracle which order the kernels use); which adjacencies take the dense form; what kernel_order reports."""
+    from ultra_torchdrug_amd import RelCSR, _lib, relcsr
+    lib = _lib.load()
+    for n_rows, n_cols in ((474, 474), (22, 22), (1, 1), (90, 90), (17, 5), (40000, 40000), (0, 3), (1 << 21, 4)):
+        for kind in (0, 1):
+            assert relcsr.dense_bytes(n_rows, n_cols, kind) == int(lib.ultra_relcsr_dense_bytes(n_rows, n_cols, kind)), (n_rows, n_cols, kind)
+    g = random_graph(3, 60, 9000, 4, unique=True)
+    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), None, 60, 60, 4, builder="torch")
+    assert csr.dense_form and csr.fwd.dense is None                     # CPU: the decision only, no matrix
+    assert csr.kernel_order("add", "mul", 1024) == (0, True) and csr.kernel_order("add", "add", 64) == (0, False)
+    assert csr.kernel_order("max", "mul", 64) == (csr.piece_len, False) and csr.kernel_order("add", "mul", 24) == (csr.piece_len, False)
+    thin = random_graph(3, 400, 1500, 4, unique=True)
+    assert not RelCSR(_t(thin["dst"]), _t(thin["src"]), _t(thin["rel"]), None, 400, 400, 4, builder="torch").dense_form
+    weighted = random_graph(3, 60, 9000, 4, unique=True, weights=True)
+    assert not RelCSR(_t(weighted["dst"]), _t(weighted["src"]), _t(weighted["rel"]), _t(weighted["w"]), 60, 60, 4, builder="torch").dense_form
+
+
+def test_oracle_dense_d_relation_order_is_within_rounding_of_the_reference_order(oracle):
+    """oracle_rspmm_drelation_dense (the kernels' documented order on dense relation graphs) against the reference order and a
+    float64 evaluation of the same sum."""
+    n, F = 50, 24
+    g = random_graph(5, n, 7000, 4, unique=True)
+    rng = np.random.default_rng(2)
+    relation, x = rng.standard_normal((4, F)).astype(np.float32), rng.standard_normal((n, F)).astype(np.float32)
+    grad = rng.standard_normal((n, F)).astype(np.float32)
+    csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], None, n, n, 4)
+    out = oracle.rspmm_forward(csr_o, relation, x, "add", "mul")
+    d_rel_seq, d_x_seq = oracle.rspmm_backward(csr_o, relation, x, out, grad, "add", "mul", piece=0)
+    d_rel_dense, d_x_dense = oracle.rspmm_backward(csr_o, relation, x, out, grad, "add", "mul", piece=0, dense_relation=True)
+    assert np.array_equal(d_x_dense, d_x_seq)
+    exact = np.zeros((4, F))
+    np.add.at(exact, csr_o.rel, grad.astype(np.float64)[csr_o.row] * x.astype(np.float64)[csr_o.col])
+    scale = np.zeros((4, F))
+    np.add.at(scale, csr_o.rel, np.abs(grad.astype(np.float64)[csr_o.row] * x.astype(np.float64)[csr_o.col]))
+    for got in (d_rel_seq, d_rel_dense):
+        assert (np.abs(got - exact) <= 64 * 2.0 ** -24 * scale + 1e-6).all()
+    assert not np.array_equal(d_rel_dense, d_rel_seq)                    # a different association, as documented
 
 
 def test_torch_extension_registers_the_dispatcher_ops():

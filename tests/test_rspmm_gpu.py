@@ -69,7 +69,7 @@ def test_forward_matches_oracle(oracle, case, sum, mul):
     relation, x = _inputs(1, n, r, F)
     csr_o = oracle.coalesce_csr(g["dst"], g["src"], g["rel"], g["w"], n, n, r)
     csr = _relcsr(g, n, n, r)
-    PIECE_LEN = csr.piece_len
+    PIECE_LEN, _ = csr.kernel_order(sum, mul, F)      # 0: the plans carry their dense form (rel_graph_like: the reference order)
     want_kernel_order = oracle.rspmm_forward(csr_o, relation, x, sum, mul, piece=PIECE_LEN)
     want_sequential = oracle.rspmm_forward(csr_o, relation, x, sum, mul, piece=0)
     assert csr.n_edges == csr_o.n_edges
@@ -91,7 +91,7 @@ def test_forward_matches_oracle(oracle, case, sum, mul):
         assert _same(got, want_sequential)      # min/max do not depend on the order
     # rows that were not split must be identical to the sequential reference order
     deg = np.diff(csr_o.row_ptr)
-    short = deg <= PIECE_LEN
+    short = (deg <= PIECE_LEN) if PIECE_LEN else np.ones(len(deg), dtype=bool)
     assert _same(got[short], want_sequential[short])
 
 

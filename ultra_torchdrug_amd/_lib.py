@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ULTRA_RSPMM_LIB: load another build of the same ABI (kernel A/B runs, tools/kbench.py)
 LIB_PATH = os.environ.get("ULTRA_RSPMM_LIB") or os.path.join(_HERE, "libultra_rspmm.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SUM_OPS = {"add": 0, "min": 1, "max": 2}
 MUL_OPS = {"mul": 0, "add": 1}
@@ -36,6 +36,9 @@ class UltraSegments(ctypes.Structure):
         ("n_hot", ctypes.c_int64),
         ("hot_nodes", ctypes.c_void_p),
         ("row_ptr", ctypes.c_void_p),
+        ("dense", ctypes.c_void_p),
+        ("dense_rows", ctypes.c_int64),
+        ("dense_cols", ctypes.c_int64),
     ]
 
 
@@ -92,6 +95,9 @@ EXPORTS = (
     "ultra_relcsr_coalesce",
     "ultra_relcsr_plan_temp_bytes",
     "ultra_relcsr_plan",
+    "ultra_relcsr_dense_bytes",
+    "ultra_relcsr_dense",
+    "ultra_calibrate_gather_f32",
 )
 
 _lib = None
@@ -229,6 +235,12 @@ def load():
     lib.ultra_relcsr_plan.restype = i32
     lib.ultra_relcsr_plan.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, i64, i64, i64, vp, i64, vp, i64,
                                       vp, i64, ctypes.POINTER(i64), vp, sz, vp]
+    lib.ultra_relcsr_dense_bytes.restype = sz
+    lib.ultra_relcsr_dense_bytes.argtypes = [i64, i64, i32]
+    lib.ultra_relcsr_dense.restype = i32
+    lib.ultra_relcsr_dense.argtypes = [seg, i64, i64, i32, vp, vp]
+    lib.ultra_calibrate_gather_f32.restype = i32
+    lib.ultra_calibrate_gather_f32.argtypes = [vp, i64, vp, i64, vp, ctypes.POINTER(i64), vp]
     if lib.ultra_rspmm_abi_version() != ABI_VERSION:
         raise UltraLibraryError("ABI mismatch: library %d, binding %d" % (lib.ultra_rspmm_abi_version(), ABI_VERSION))
     _lib = lib

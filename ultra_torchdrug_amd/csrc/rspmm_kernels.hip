@@ -27,9 +27,11 @@
 #include <cstring>
 #include <mutex>
 
+#include "relgraph_dense.h"
 #include "ultra_rspmm.h"
 
-// hipError_t of the last failing HIP call on this thread; shared with relcsr_build.hip
+// hipError_t of the last failing HIP call on this thread; shared with relcsr_build.hip (hidden: -fvisibility=hidden, the
+// library exports exactly what include/ultra_rspmm.h declares)
 thread_local int ultra_detail_last_hip_error = 0;
 
 namespace {
@@ -1258,6 +1260,8 @@ int launch_rowgroup(RowGroupParams &q, bool backward, int sum_op, int mul_op, bo
 
 bool g_no_rowgroup = false;
 bool g_no_concurrent_tiles = false;
+bool g_no_dense = false;
+
 
 // Runs one plan: segment_kernel over the chunk schedule, then fixup_kernel over the split rows.
 template <int KIND>
@@ -1310,6 +1314,18 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
     }
     auto stamp = [&](hipEvent_t ev) -> hipError_t { return hipEventRecord(ev, stream); };
     if (ev_start != nullptr) HIP_TRY(stamp(ev_start));
+    // dense relation graphs: the sum as a product with the plan's 0/1 matrix on the exact-f32 matrix cores -- the reference
+    // order for every row, no pieces, no fix-up pass (relgraph_dense.hip)
+    if (seg->dense != nullptr && !g_no_dense && !g_force_general && !g_no_quad && !g_no_x_lds) {
+        ultra_detail::DenseCall call{seg, KIND, sum_op, mul_op, p.relation, p.input, p.grad, p.add_rows, p.bnode, p.bvec, p.bdim,
+                                     p.out, workspace, workspace_bytes, gather_rows, gather2_rows, n_rel, F};
+        if (ultra_detail::dense_applies(call)) {
+            rc = ultra_detail::dense_launch(call, stream);
+            if (rc) return rc;
+            if (ev_stop != nullptr) HIP_TRY(stamp(ev_stop));
+            return ULTRA_OK;
+        }
+    }
     // big graphs of short rows (node ids outside the packed word, no split rows, row pointers present): one row per
     // 16-lane group (rowgroup.inc); same sequential order per row as every other kernel, so the same bits
     bool use_rowgroup = false;
@@ -1528,6 +1544,7 @@ int ultra_rspmm_force_general_path(int on) {
     g_no_rowgroup = (on & 8) != 0;        // bit 3: chunked kernels where one row per group (rowgroup_kernel) would run
     g_wide_groups = (on & 16) != 0;       // bit 4: rowgroup_kernel with 32 / 64 lanes per row even for cache-sized inputs
     g_no_concurrent_tiles = (on & 32) != 0;   // bit 5: quad_kernel walks a label's column tiles one after the other
+    g_no_dense = (on & 64) != 0;          // bit 6: the edge list of a plan that carries a dense form (relgraph_dense.hip)
     return ULTRA_OK;
 }
 

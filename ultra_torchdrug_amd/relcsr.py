@@ -62,6 +62,26 @@ HOT_MAX = 512        # at most this many cached rows
 HOT_MIN_COVERAGE = 0.2   # build a hot-row cache only if it serves at least this fraction of the gathers
 _INT32_MAX = 2 ** 31 - 1
 
+# Dense form of a plan (csrc/relgraph_dense.hip; include/ultra_rspmm.h, ABI 7): unit-weight adjacencies over exactly 4 relation
+# types -- the relation graphs of /root/reference/ultra/rel_model.py:99-143 -- whose edges fill at least this fraction of the
+# n_dst x n_src x 4 slots run their sum aggregations as a product with a 0/1 matrix on the exact-f32 matrix cores: the
+# reference's sequential order for every row.  The product costs the same whatever the density, the edge walk is linear in the
+# edges: the crossover is measured in DESIGN.md (tools/dense_crossover.py).  ULTRA_DENSE_RELGRAPH=0 switches the form off.
+DENSE_RELGRAPH = os.environ.get("ULTRA_DENSE_RELGRAPH", "1") != "0"
+DENSE_MIN_DENSITY = float(os.environ.get("ULTRA_DENSE_MIN_DENSITY", "0.08"))
+DENSE_TYPES = 4
+
+
+def dense_bytes(n_rows, n_cols, kind):
+    """Size of a plan's dense matrix -- ``ultra_relcsr_dense_bytes`` restated (the decision must not depend on the device:
+    CPU-side RelCSR objects tell the tests' oracle which summation order the kernels use).  0: shape not supported."""
+    if n_rows <= 0 or n_cols <= 0 or n_rows > (1 << 20) or n_cols > (1 << 20):
+        return 0
+    n_vt = (n_rows + 15) // 16
+    round_ = 16 if kind == 0 else 32
+    size = n_vt * 64 * ((n_cols + round_ - 1) // round_ * round_) + (1024 if kind == 0 else 512)       # + slack the kernels may read
+    return size if size < (1 << 31) else 0
+
 
 class Segments:
     """One reduction plan; owns the device tensors and the ``ultra_segments`` struct pointing at them."""
@@ -91,6 +111,7 @@ class Segments:
         self.hot_nodes, self.n_hot = None, 0
         self.packed, self.packed_src_shift = None, 0
         self.row_ptr = None
+        self.dense, self.dense_rows, self.dense_cols = None, 0, 0
         if builder is None:
             builder = os.environ.get("ULTRA_RELCSR_BUILDER") or ("native" if row.is_cuda else "torch")
         self.builder = "torch" if (hot_cache or not row.is_cuda) else builder
@@ -207,6 +228,23 @@ class Segments:
         s.n_hot = self.n_hot
         s.hot_nodes = self.hot_nodes.data_ptr() if self.hot_nodes is not None else None
         s.row_ptr = self.row_ptr.data_ptr() if self.row_ptr is not None else None
+        s.dense = self.dense.data_ptr() if self.dense is not None else None
+        s.dense_rows, s.dense_cols = self.dense_rows, self.dense_cols
+
+    def attach_dense(self, n_rows, n_cols, kind):
+        """Build the plan's 0/1 matrix natively (``ultra_relcsr_dense``) and hang it on the struct.  ``kind`` 0: rows of the
+        plan are nodes (forward / d_input); 1: rows are the 4 relation types (d_relation), ``n_rows`` = destination nodes."""
+        lib = _lib.load()
+        size = int(lib.ultra_relcsr_dense_bytes(n_rows, n_cols, kind))
+        if size == 0 or self.weight is not None or not self.row.is_cuda:
+            return False
+        dense = torch.empty(size // 4, dtype=torch.int32, device=self.row.device)
+        with torch.cuda.device(self.row.device):
+            _lib.check(lib.ultra_relcsr_dense(self.pointer, n_rows, n_cols, kind, dense.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
+        self.dense, self.dense_rows, self.dense_cols = dense, int(n_rows), int(n_cols)
+        self._refresh_struct()
+        return True
 
     @property
     def pointer(self):
@@ -362,6 +400,18 @@ class RelCSR:
         self.piece_len = int(self._requested[1] or (auto_piece if self._requested[0] is None else 4 * self.chunk_edges))
         self._opts.update(chunk_edges=self.chunk_edges, piece_len=self.piece_len)
         self._fwd = self._by_src = self._by_rel = None
+        # dense form (relation graphs): a property of the GRAPH alone -- same answer for a CPU copy of it
+        self.dense_form = bool(
+            DENSE_RELGRAPH and n_rel == DENSE_TYPES and unit and self.n_edges > 0 and not wide_ids and not hot_cache
+            and self.n_edges >= DENSE_MIN_DENSITY * float(n_dst) * float(n_src) * DENSE_TYPES
+            and dense_bytes(n_dst, n_src, 0) and dense_bytes(n_src, n_dst, 0) and dense_bytes(n_dst, n_src, 1))
+
+    def kernel_order(self, sum="add", mul="mul", F=64):
+        """``(piece, dense_d_relation)``: the summation order the library uses for this adjacency and call -- what the tests'
+        oracle needs.  ``piece`` (forward, d_input): 0 = strictly sequential per row (the reference order; the dense form), else
+        the plans' piece length.  ``dense_d_relation``: d_relation in the dense form's documented order (include/ultra_rspmm.h)."""
+        dense = bool(getattr(self, "dense_form", False) and self.unit_weight and sum == "add" and F % 16 == 0 and F * 4 < (1 << 24))
+        return (0 if dense else self.piece_len), (dense and mul == "mul")
 
     def _coalesce_native(self, dst, src, rel, weight, dims=None):
         """``ultra_relcsr_coalesce`` (csrc/relcsr_build.hip): radix sort of the 64-bit triple key + duplicate merge.
@@ -421,6 +471,8 @@ class RelCSR:
             self._fwd = Segments(self.dst, self.src, None, self.rel_id, self._w(), self.shape[0],
                                  lds_rel_rows=self.shape[2], n_gather_rows=self.shape[1], n_node_a=self.shape[1],
                                  n_rel_table=self.shape[2], **self._opts)
+            if self.dense_form:
+                self._fwd.attach_dense(self.shape[0], self.shape[1], 0)
         return self._fwd
 
     def _reorder(self, first, second, third, dims):
@@ -449,6 +501,8 @@ class RelCSR:
             self._by_src = Segments(src, dst, None, rel, self._w(order), n_src,
                                     lds_rel_rows=n_rel, n_gather_rows=n_dst, n_node_a=n_dst, n_rel_table=n_rel,
                                     **self._opts)
+            if self.dense_form:
+                self._by_src.attach_dense(n_src, n_dst, 0)
         return self._by_src
 
     @property
@@ -462,6 +516,8 @@ class RelCSR:
             self._by_rel_order = order
             self._by_rel = Segments(rel, src, dst, rel, self._w(order), n_rel, n_node_a=n_src, n_rel_table=n_rel,
                                     **self._opts)
+            if self.dense_form:
+                self._by_rel.attach_dense(n_dst, n_src, 1)
         return self._by_rel
 
     @property
@@ -472,7 +528,14 @@ class RelCSR:
         per graph; a reweighted RelCSR shares its base's."""
         base = getattr(self, "_base", None)
         if base is not None:
-            return base.frontier_index
+            return base._frontier_index_for(self.dense_form)
+        return self._frontier_index_for(self.dense_form)
+
+    def _frontier_index_for(self, dense_form):
+        """Where the plans carry their dense form the full kernels never split a row (the reference order for every row), so
+        the frontier kernel must not either: every edge gets rank 0 -- one piece per row, summed in (destination, relation)
+        order.  (The first FB15k237Inductive-v1-shaped run caught the mix: a source's four parallel edges straddling a
+        256-edge piece boundary of a row the dense kernels sum sequentially, scores off by one ulp.)"""
         if getattr(self, "_frontier_index", None) is None:
             _ = self.by_src                                        # builds the (src, dst, rel) order
             n_dst, n_src, _n_rel = self.shape
@@ -484,7 +547,11 @@ class RelCSR:
             torch.cumsum(torch.bincount(self.src, minlength=n_src), 0, out=src_ptr[1:])
             self._frontier_index = (src_ptr.to(torch.int32).contiguous(),
                                     rank_fwd[self._by_src_order].to(torch.int32).contiguous())
-        return self._frontier_index
+        if not dense_form:
+            return self._frontier_index
+        if getattr(self, "_frontier_index_dense", None) is None:
+            self._frontier_index_dense = (self._frontier_index[0], torch.zeros_like(self._frontier_index[1]))
+        return self._frontier_index_dense
 
     @property
     def frontier_runs(self):
@@ -518,6 +585,7 @@ class RelCSR:
         w = torch.zeros(self.n_edges, dtype=torch.float32, device=self.device)
         w.index_add_(0, self.edge_of_input, edge_weight.to(torch.float32))
         other.weight, other.unit_weight = w, False
+        other.dense_form = False                    # per-edge weights: the edge list is walked
         # the object that owns the sorted plans and their permutations: reweighting a reweighted RelCSR goes back to it
         other._base = getattr(self, "_base", None) or self
         other._fwd = other._by_src = other._by_rel = None
@@ -547,6 +615,7 @@ class RelCSR:
         other.dst, other.src, other.rel_id = self.dst, self.src, self.rel_id
         other.edge_of_input, other.n_edges = self.edge_of_input, self.n_edges
         other.weight, other.unit_weight = w[0][:E], False
+        other.dense_form = False
         other._base = base
         other._fwd = plans[0].with_weight_buffer(w[0])
         other._by_src = plans[1].with_weight_buffer(w[1])
