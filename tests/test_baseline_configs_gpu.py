@@ -175,3 +175,27 @@ def test_fb15k237_inductive_v1_shape_zero_shot_inference_equals_oracle_path():
         pred_host = torch.cat([task.predict(test[i:i + 16]) for i in range(0, len(test), 16)])
     diff = (pred_host - pred_cpu).abs().max().item()
     assert diff <= 1e-4, "product CPU path vs oracle path: %.3g" % diff
+
+
+def test_end_to_end_fixture_hip_path():
+    """tests/golden/e2e_codexs.json: the HIP path reproduces the COMMITTED scores (SHA-256 of the kernels' order, bit for bit) and
+    int64 ranks of the seeded S-codexs task -- a change that moved the HIP path and the oracle together would pass every live
+    comparison and fail here (VERDICT r4 missing 7)."""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_e2e_golden as G
+    want = json.load(open(os.path.join(here, "golden", "e2e_codexs.json")))
+    task, batch = G.build_task()
+    dev = _dev()
+    task.to(dev)
+    with torch.no_grad():
+        pred = task.predict(batch.to(dev))
+        ranks = task.rank_batch(batch.to(dev), pred=pred)
+    got = G.summary(pred, ranks)
+    assert got["ranks"] == want["kernel_order"]["ranks"] == want["reference_order"]["ranks"]
+    assert got["scores_sha256"] == want["kernel_order"]["scores_sha256"]
+    # and within rounding of the reference order's scores
+    assert abs(got["scores_sum"] - want["reference_order"]["scores_sum"]) <= 1e-5 * want["reference_order"]["scores_abs_sum"]

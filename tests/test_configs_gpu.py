@@ -80,6 +80,30 @@ def test_stress_graph_at_full_size(oracle):
         assert np.array_equal(got[rows].cpu().numpy(), want), sum_op
         del got
 
+    # ---- (ii) the WHOLE output against the reference's own ATen definition (ultra/layer.py:249-255,275-285: gather, (*|+),
+    # scatter), no oracle in between: sums within the bound of two summation orders, min / max EQUAL.
+    # The definition's (E, F) messages are 25.6 GB each at this size: evaluated over four slices of the edge list.
+    with torch.no_grad():
+        want_sum, scale = torch.zeros(N, F, device=dev), torch.zeros(N, F, device=dev)
+        fmax = torch.finfo(torch.float32).max
+        want_min, want_max = torch.full((N, F), fmax, device=dev), torch.full((N, F), -fmax, device=dev)
+        for e0 in range(0, E, 25_000_000):
+            sl = slice(e0, min(e0 + 25_000_000, E))
+            d_, s_, r_ = csr.dst[sl], csr.src[sl], csr.rel_id[sl]
+            message = relation[r_] * x[s_]                                     # layer.py:249-255 (distmult), unit weights
+            want_sum.index_add_(0, d_, message)                                # scatter_add (layer.py:275-276)
+            scale.index_add_(0, d_, message.abs())
+            message = relation[r_] + x[s_]                                     # transe, for the order-free aggregates
+            index = d_.unsqueeze(-1).expand_as(message)
+            want_min.scatter_reduce_(0, index, message, reduce="amin", include_self=True)
+            want_max.scatter_reduce_(0, index, message, reduce="amax", include_self=True)
+            del message, index
+        assert ((out - want_sum).abs() <= 1e-5 * scale + 1e-6).all(), "sum differs from the ATen definition beyond the bound"
+        del want_sum, scale
+        assert torch.equal(UF.rspmm_forward(csr, relation, x, "min", "add"), want_min), "min differs from the ATen definition"
+        assert torch.equal(UF.rspmm_forward(csr, relation, x, "max", "add"), want_max), "max differs from the ATen definition"
+        del want_min, want_max
+
     # ---- backward at size: d_input on a subset of source rows, d_relation of two relations
     grad = torch.randn(N, F, device=dev, generator=gen)
     d_x, d_rel = UF.rspmm_backward(csr, relation, x, None, grad, "add", "mul")

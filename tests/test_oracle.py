@@ -3,6 +3,7 @@ definition (ultra/layer.py:232-296) restated in numpy fp64, (iii) algebraic prop
 (v) the committed seeded golden vectors.  No GPU, no product code."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -195,3 +196,19 @@ def test_filtered_rank(oracle):
     pos = pred[np.arange(7), target][:, None]
     want = ((pos <= pred) & mask).sum(-1) + 1
     assert np.array_equal(oracle.filtered_rank(pred, mask, target), want)
+
+
+def test_end_to_end_fixture_oracle_path(oracle):
+    """tests/golden/e2e_codexs.json (tests/golden/make_e2e_golden.py): the oracle path must keep producing the
+    committed int64 ranks and score checksums of the seeded S-codexs task -- in the reference's order and in the kernels' order."""
+    import json
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_e2e_golden as G
+    want = json.load(open(os.path.join(HERE, "golden", "e2e_codexs.json")))
+    for name, piece in (("reference_order", 0), ("kernel_order", None)):
+        pred, ranks = G.oracle_side(piece)
+        got = G.summary(pred, ranks)
+        assert list(pred.shape) == want["score_shape"]
+        assert got["ranks"] == want[name]["ranks"], name
+        assert got["scores_sha256"] == want[name]["scores_sha256"], name
+    assert want["reference_order"]["ranks"] == want["kernel_order"]["ranks"]     # the orders differ in the last bits only

@@ -31,7 +31,12 @@ from graphs import kg_graph
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = {"S-fb15k237": (14541, 272115, 237), "S-wn18rr": (40943, 86835, 11), "S-codexs": (2034, 32888, 42)}
+SHAPES = {"S-fb15k237": (14541, 272115, 237), "S-wn18rr": (40943, 86835, 11), "S-codexs": (2034, 32888, 42),
+          "S-codexm": (17050, 185584, 51)}
+BASE = ["S-fb15k237", "S-wn18rr", "S-codexs"]
+# config 4 (pretrain_3g.yaml:45-47: B = 64 per GPU => F = 4 096, 64 column tiles) on its three graphs: the
+# materialised message of the definition is E x F fp32 = 8.9 GB on S-fb15k237
+PRETRAIN_WIDTH = [("S-fb15k237", 4096, False), ("S-wn18rr", 4096, False), ("S-codexm", 4096, False)]
 # (width F, per-edge weights): B = 2 with and without weights; the configs' widths F = B * 64 = 1 024 and 2 * B * 64 = 2 048
 WIDTHS = [(128, False), (128, True), (1024, False), (2048, False), (2048, True)]
 
@@ -83,8 +88,7 @@ def reference_rspmm(dst, src, rel, w, relation, x, n_rows, sum, mul):
     return out.scatter_reduce(0, index, message, reduce=reduce, include_self=False)
 
 
-@pytest.mark.parametrize("name", list(SHAPES))
-@pytest.mark.parametrize("F,weights", WIDTHS)
+@pytest.mark.parametrize("name,F,weights", [(n, f, w) for n in BASE for f, w in WIDTHS] + PRETRAIN_WIDTH)
 @pytest.mark.parametrize("sum", ["add", "min", "max"])
 @pytest.mark.parametrize("mul", ["mul", "add"])
 def test_operator_equals_reference_definition_at_baseline_shapes(name, F, weights, sum, mul):
@@ -417,3 +421,68 @@ def test_whole_finetune_step_at_wn18rr_batch_16_equals_the_aten_definition():
         assert e_hip <= 4 * e_aten + 2e-3 * s, "%s: HIP %.3g vs ATen-fp32 %.3g away from fp64 (scale %.3g)" % (k, e_hip, e_aten, s)
     print("finetune step vs fp64 definition: worst relative gradient error HIP %.2e, ATen-fp32 %.2e"
           % (max(v[0] for v in worst.values()), max(v[1] for v in worst.values())))
+
+
+@pytest.mark.parametrize("name", ["S-wn18rr", "S-codexm", "S-fb15k237"])
+def test_whole_pretraining_step_at_batch_64_equals_the_aten_definition(name):
+    """BASELINE config 4 at size and at ITS width: ONE training step per pre-training graph at B = 64 (F = 4 096:
+    64 column tiles, the launch shape of pretrain_3g.yaml:45-47), 128 strict negatives, self-adversarial BCE -- loss and EVERY
+    parameter gradient of the HIP step (masked d_relation of the first / last layer, grouped projections, boundary-row backward,
+    candidate-row score head, fused loss, the dense relation-graph kernels where the relation graph takes them) against the step
+    computed entirely through the reference's ATen definition (ultra/layer.py:232-296, ultra/model.py:57-74, ultra/task.py:160-195)
+    in fp32 and fp64; same yardstick as the B = 16 step above.  The definition's layers are re-computed in the backward
+    (torch.utils.checkpoint around each layer, definition side only): its materialised messages are 18 GB per tensor and layer
+    in fp64 on S-fb15k237 -- and 29 GB on that graph's complete relation graph -- where autograd would keep three per layer."""
+    import torch.utils.checkpoint as cp
+    from aten_definition import aten_definition
+    from ultra_torchdrug_amd import layer as UL
+    dev = _dev()
+    B = 64
+    task, triples, n_fact = _transductive(name, 16, dev, num_negative=128)
+    task.train()
+    batch = triples[torch.randperm(n_fact, generator=torch.Generator().manual_seed(7))[:B].to(dev)]
+    torch.manual_seed(7)
+    negatives = task._strict_negative(*batch.t())
+    assert negatives.shape == (B, 128)
+
+    def step():
+        task.zero_grad(set_to_none=True)
+        task._static_negative = negatives
+        try:
+            loss, metric = task(batch)
+            loss.backward()
+        finally:
+            task._static_negative = None
+        grads = {k: p.grad.detach().double().clone() for k, p in task.named_parameters() if p.grad is not None}
+        return float(loss.detach()), grads
+
+    plain_forward = UL._RelationalConvBase.forward
+
+    def checkpointed(self, graph, input, *args, **kwargs):
+        if not torch.is_grad_enabled() or not input.requires_grad:
+            return plain_forward(self, graph, input, *args, **kwargs)
+        return cp.checkpoint(lambda x: plain_forward(self, graph, x, *args, **kwargs), input, use_reentrant=False)
+
+    loss_hip, g_hip = step()
+    torch.cuda.empty_cache()
+    UL._RelationalConvBase.forward = checkpointed
+    try:
+        with aten_definition(task):
+            loss_aten, g_aten = step()
+        torch.cuda.empty_cache()
+        with aten_definition(task, double=True):
+            loss_true, g_true = step()
+    finally:
+        UL._RelationalConvBase.forward = plain_forward
+    task.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()
+    assert g_hip.keys() == g_aten.keys() == g_true.keys() and len(g_true) == 6 * 8 + 4 + 6 * 5        # every trained tensor
+    assert abs(loss_hip - loss_true) <= 4 * abs(loss_aten - loss_true) + 1e-5 * abs(loss_true)
+    worst = {}
+    for k in g_true:
+        s = g_true[k].abs().max().item() + 1e-12
+        e_hip, e_aten = (g_hip[k] - g_true[k]).abs().max().item(), (g_aten[k] - g_true[k]).abs().max().item()
+        worst[k] = (e_hip / s, e_aten / s)
+        assert e_hip <= 4 * e_aten + 2e-3 * s, "%s: HIP %.3g vs ATen-fp32 %.3g away from fp64 (scale %.3g)" % (k, e_hip, e_aten, s)
+    print("%s pre-training step (B = 64) vs fp64 definition: worst relative gradient error HIP %.2e, ATen-fp32 %.2e"
+          % (name, max(v[0] for v in worst.values()), max(v[1] for v in worst.values())))

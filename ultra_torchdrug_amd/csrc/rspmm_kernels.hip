@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -1575,8 +1576,11 @@ int ultra_rspmm_profile_next(void *start_event, void *stop_event) {
 }
 
 size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg, int64_t F) {
-    if (seg == nullptr || F <= 0 || seg->n_pieces <= 0) return 0;
-    return (size_t)seg->n_pieces * (size_t)F * sizeof(float);
+    if (seg == nullptr || F <= 0) return 0;
+    int64_t rows = seg->n_pieces > 0 ? seg->n_pieces : 0;
+    // d_relation plan in its dense form: one tile sum per 16 destination nodes and relation type (relgraph_dense.hip)
+    if (seg->dense != nullptr && seg->n_rows == 4 && seg->node_b != nullptr) rows = std::max<int64_t>(rows, 4 * ((seg->dense_rows + 15) / 16));
+    return (size_t)rows * (size_t)F * sizeof(float);
 }
 
 int ultra_rspmm_forward_f32(const ultra_segments *fwd, const float *relation, const float *input, const float *add_rows,

@@ -87,7 +87,7 @@ def _stream():
 
 
 def _workspace(seg, F, device):
-    n = seg.n_pieces * F
+    n = seg.workspace_rows * F
     if n == 0:
         return None, 0
     ws = torch.empty(n, dtype=torch.float32, device=device)
@@ -315,7 +315,7 @@ def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mu
         by_src = csr.by_src if need_input else None
         by_rel = csr.by_rel if need_relation else None
         lib = _lib.load()
-        n_ws = max(by_src.n_pieces if by_src is not None else 0, by_rel.n_pieces if by_rel is not None else 0) * F
+        n_ws = max(by_src.workspace_rows if by_src is not None else 0, by_rel.workspace_rows if by_rel is not None else 0) * F
         ws = torch.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
         with torch.cuda.device(dev):
             _lib.check(lib.ultra_rspmm_backward_active_f32(
@@ -342,7 +342,7 @@ def rspmm_backward(csr, relation, input, output, output_grad, sum="add", mul="mu
             relation, input, output, output_grad, d_input, d_input_add is not None, csr.shape[1], csr.shape[0], sum_op, mul_op)
         return d_input, (d_rel if need_relation else None)
     lib = _lib.load()
-    n_ws = max(by_src.n_pieces if by_src is not None else 0, by_rel.n_pieces if by_rel is not None else 0) * F
+    n_ws = max(by_src.workspace_rows if by_src is not None else 0, by_rel.workspace_rows if by_rel is not None else 0) * F
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
     with torch.cuda.device(dev):
         _lib.check(lib.ultra_rspmm_backward_accumulate_f32(

@@ -247,6 +247,15 @@ class Segments:
         return True
 
     @property
+    def workspace_rows(self):
+        """Rows of F floats a call over this plan needs as scratch (``ultra_rspmm_workspace_bytes``): the piece sums of the edge
+        walk; for a d_relation plan in its dense form also one tile sum per 16 destination nodes and relation type."""
+        rows = self.n_pieces
+        if self.dense is not None and self.node_b is not None and self.n_rows == 4:
+            rows = max(rows, 4 * ((self.dense_rows + 15) // 16))
+        return rows
+
+    @property
     def pointer(self):
         return ctypes.byref(self.struct)
 
