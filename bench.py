@@ -527,6 +527,11 @@ def flat_config_keys(configs):
     put("cfg4_step_ms_max_over_ranks", 4, "step_ms_max_over_ranks")
     put("cfg4_edge_messages_per_s_nominal", 4, "entity_edge_messages_per_s_nominal")
     put("cfg4_allreduce_exposed_ms_per_step", 4, "allreduce_exposed_ms_per_step")
+    put("cfg4_collective_backend", 4, "collective_backend")
+    put("cfg4_step_mode", 4, "step_mode")
+    put("cfg4_step_modes_agree", 4, "step_modes_agree")
+    put("cfg4_step_ms_16_cus_reserved", 4, "step_ms_max_over_ranks_16_cus_reserved")
+    put("cfg4_allreduce_exposed_ms_16_cus_reserved", 4, "allreduce_exposed_ms_per_step_16_cus_reserved")
     put("cfg4_eager_step_ms", 4, "eager_step_ms")
     put("cfg5_frac", 5, "frac_of_hbm_peak")
     put("cfg5_fwd_ms", 5, "operator_fwd_ms")
@@ -641,8 +646,14 @@ def pretrain_timing(dev, seed, rank, world, ranks, quick):
         loop(same[:3], True)
         with_comm, _, _ = loop(same, True)
         without, _, _ = loop(same, False)                            # LAST: the ranks' weights drift apart from here on
-        mode = next(iter(graphed.steps.values())).mode
-        out.update({"gradient_allreduce": "engine.GradientReducer: %d buckets in %d groups (one all-reduce per group), %d fp32 "
+        modes = graphed.modes
+        mode = "/".join(sorted(set(modes.values())))
+        # every rank and context should be in the same mode (a capture whose phased backward does not verify drops to
+        # "after" with a warning, possibly on one rank only: the collectives still match, the overlap is lost there)
+        code = float(sum({"phased": 0, "after": 1, "in_graph": 2, "single": 3}.get(m, 4) * 10 ** i for i, m in enumerate(modes[k] for k in sorted(modes))))
+        agree = ranks.max([code])[0] == -ranks.max([-code])[0] and len(set(modes.values())) == 1
+        out.update({"step_modes": modes, "step_modes_agree": bool(agree), "collective_backend": dist.get_backend(),
+                    "gradient_allreduce": "engine.GradientReducer: %d buckets in %d groups (one all-reduce per group), %d fp32 "
                                           "parameters, %s, side stream; step mode `%s` (phased: 3 captured phases, each phase's group "
                                           "all-reduced while the next phase replays; after: one graph, the groups after the replay); "
                                           "+ 1 packed metric all-reduce"
@@ -693,6 +704,36 @@ def real_data_metrics(data_dir, ckpt, dev, B):
             # two queries per test triple, layers 2-6 over all E edges each (the first layer's frontier edges not counted)
             "entity_edge_messages_per_s": 2 * 5 * und.relcsr.n_edges * len(test) / seconds if seconds > 0 else None,
             "metrics": {k: float(v) for k, v in metric.items()}}
+
+
+class Phases:
+    """World > 1 only (the first real N-GPU run must not hang silently): every rank names the phase it
+    enters on stderr, and a phase that overruns its limit makes the rank EXIT non-zero (a plain exit from a timer thread --
+    never a re-exec of a process that has touched the GPU), so the launcher tears the job down and the driver sees which
+    phase and which rank stopped."""
+
+    def __init__(self, rank, world, limit_s=600.0):
+        self.rank, self.on, self.limit, self.timer, self.t0 = rank, world > 1, limit_s, None, time.perf_counter()
+
+    def enter(self, name, limit_s=None):
+        if not self.on:
+            return
+        import threading
+        self.done()
+        limit = float(limit_s or self.limit)
+        print("[bench rank %d +%.1fs] %s (limit %.0f s)" % (self.rank, time.perf_counter() - self.t0, name, limit), file=sys.stderr, flush=True)
+        self.timer = threading.Timer(limit, self._expire, args=(name, limit))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _expire(self, name, limit):
+        print("[bench rank %d] phase `%s` exceeded %.0f s: exiting with code 3" % (self.rank, name, limit), file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def done(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
 
 
 def distinct_devices(dev, world, share):
@@ -747,6 +788,8 @@ def main():
         raise SystemExit("bench.py: rank %d has no device (%d visible)" % (local_rank, n_dev))
     if share:
         local_rank %= n_dev
+    phases = Phases(rank, world)
+    phases.enter("init_process_group (%s)" % ("gloo, shared GPU" if share else "nccl = RCCL"), 300)
     # the process group comes first: RCCL is initialised before this process makes any other GPU call
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -769,6 +812,7 @@ def main():
     torch.backends.cudnn.allow_tf32 = False
 
     # ---------------- graph, split, model (identical on every rank) ----------------
+    phases.enter("graph, plans, model")
     from ultra_torchdrug_amd.data import SHAPES
     n_node, n_fact_shape, n_rel = SHAPES[args.workload]
     n_test = min(2048, n_fact_shape // 20)
@@ -835,6 +879,7 @@ def main():
             torch.cuda.synchronize()
             return None
 
+    phases.enter("capture of the evaluation step")
     graphed = None if args.eager else capture()
 
     def step(i, g=None):
@@ -854,6 +899,7 @@ def main():
             same = same and bool(torch.equal(got, task.predict(batch)))
         return same
 
+    phases.enter("warm-up, barrier, timed region")
     with torch.no_grad():
         for i in range(args.warmup):
             step(i)
@@ -885,6 +931,7 @@ def main():
         frontier_visited = sum(frontier_per_batch[(args.warmup + i) % n_batches] for i in range(args.steps))
 
         # ---- after the timed region: the dominant kernel alone, and the other per-step numbers
+        phases.enter("per-kernel timings after the timed region")
         gen = torch.Generator(device=dev).manual_seed(DEFAULT_SEED)
         xk = torch.randn(n_node, Fk, device=dev, generator=gen)
         rk = torch.randn(R2, Fk, device=dev, generator=gen)
@@ -966,8 +1013,21 @@ def main():
     if world > 1 and args.configs:                   # config 4 with the RCCL gradient all-reduce: every rank takes part
         del xk, rk
         torch.cuda.empty_cache()
+        phases.enter("config 4: capture of three graphs + steps with the gradient all-reduce", 900)
         pretrain_n = pretrain_timing(dev, DEFAULT_SEED, rank, world, ranks, quick=args.steps < 100)
+        if not share:
+            # the same steps with 16 compute units left free for RCCL's kernels (ultra_rspmm_reserve_cus): persistent
+            # 256-workgroup grids may starve a collective that overlaps them -- an A/B the first N-GPU run records
+            phases.enter("config 4 again with 16 compute units reserved for the collectives", 900)
+            lib.ultra_rspmm_reserve_cus(16)
+            try:
+                reserved = pretrain_timing(dev, DEFAULT_SEED, rank, world, ranks, quick=True)
+            finally:
+                lib.ultra_rspmm_reserve_cus(0)
+            for key in ("step_ms_max_over_ranks", "same_graphs_step_ms_with_allreduce", "allreduce_exposed_ms_per_step"):
+                pretrain_n[key + "_16_cus_reserved"] = reserved.get(key)
         xk = rk = None
+    phases.enter("MRR, evaluation runs, configs (rank 0), final barrier", 1800)
 
     k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     algo = bytes_algo(E, n_node, R2, Fk)
@@ -1192,6 +1252,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    phases.done()
 
 
 if __name__ == "__main__":

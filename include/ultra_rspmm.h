@@ -124,6 +124,12 @@ int ultra_rspmm_event_elapsed_ms(void *start_event, void *stop_event, float *ms_
  * LDS-message form would run.  All paths return identical bits. */
 int ultra_rspmm_force_general_path(int on);
 
+/* Process-wide: size every persistent grid for `n` compute units fewer than the device has (default 0).  The plan kernels run
+ * one workgroup per compute unit for the life of a launch; a collective overlapped with them on a side stream (RCCL's kernels
+ * during the phased training step) then finds no free compute unit until workgroups retire.  Affects launches (and hipGraph
+ * captures) made AFTER the call; results never depend on it. */
+int ultra_rspmm_reserve_cus(int n);
+
 /* Scratch bytes a call over `seg` with row width F needs (piece partial sums). */
 size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg_host, int64_t F);
 
@@ -193,8 +199,11 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
  *                 prefix count of `src or dst differs from the previous edge`); fixes every listed row's slot, so the list
  *                 is written without atomics or counters and the same way on every launch
  *   out         : [n_dst, n_query, 64], written completely
- *   row_list    : int32 scratch of row_list_len entries, at least n_query * (max runs of any source node + 1) (slots beyond
- *                 row_list_len are neither written nor read: rows whose slot does not fit would keep the constant -- size it)
+ *   row_list    : int32 scratch of row_list_len entries
+ *   max_runs    : the largest number of (source, destination) runs any ONE source node has in the plan, i.e. of distinct
+ *                 destinations (a property of the graph, like run_prefix); row_list_len < n_query * (max_runs + 1) is refused
+ *                 with ULTRA_ERR_BAD_SHAPE -- a shorter list could not hold every query's slots, and rows without a slot would
+ *                 keep their raw sums with no epilogue applied
  *   list_offset : int32 scratch [n_query + 1]
  * Sum aggregation of DistMult messages with a FINITE relation table (as ultra_rspmm_frontier_f32).
  * ultra_first_layer_sparse_supported: the shapes this entry takes (message table of n_rel rows in LDS, n_query <= 128,
@@ -204,8 +213,8 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
                                  const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
                                  const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
                                  const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                                 float *out, int32_t *row_list, int64_t row_list_len, int32_t *list_offset, int64_t n_dst,
-                                 int64_t n_rel, void *stream);
+                                 float *out, int32_t *row_list, int64_t row_list_len, int64_t max_runs, int32_t *list_offset,
+                                 int64_t n_dst, int64_t n_rel, void *stream);
 
 /* d_input of the FIRST layer's rspmm in training, at the rows that are used: that layer's input is the boundary
  * (/root/reference/ultra/model.py:106-107,116-120), whose gradient autograd consumes at row (boundary_node[q], query block q)

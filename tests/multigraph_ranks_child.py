@@ -71,7 +71,14 @@ def main():
     flat = torch.cat([p.detach().reshape(-1).double() for p in twin.parameters()])
     both = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
-    print(json.dumps({"rank": rank, "buckets": len(reducer_g.buckets), "warm_launches": after_init, "per_step": per_step,
+    # what ran the collectives, and on how many DIFFERENT devices (the parent asserts nccl + distinct devices on a multi-GPU node)
+    props = torch.cuda.get_device_properties(dev)
+    ident = torch.tensor([(int(getattr(props, "pci_domain_id", 0)) << 32) | (int(getattr(props, "pci_bus_id", 0)) << 16)
+                          | int(getattr(props, "pci_device_id", dev.index or 0))], dtype=torch.int64, device=dev)
+    idents = [torch.zeros_like(ident) for _ in range(world)]
+    dist.all_gather(idents, ident)
+    print(json.dumps({"rank": rank, "backend": dist.get_backend(), "distinct_devices": len({int(t.item()) for t in idents}),
+                      "modes": graphed.modes, "buckets": len(reducer_g.buckets), "warm_launches": after_init, "per_step": per_step,
                       "captured": sorted(graphed.steps), "graphed_equals_eager": equal, "losses_equal": losses_g == losses_e,
                       "ranks_hold_equal_parameters": bool(all(torch.equal(both[0], b) for b in both[1:])),
                       "finite": bool(torch.isfinite(flat).all())}), flush=True)

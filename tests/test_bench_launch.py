@@ -59,3 +59,9 @@ def test_gpus_2_launches_its_own_ranks_and_times_the_pretraining_step_with_the_r
     assert "cfg4_allreduce_exposed_ms_per_step" in cfg and cfg["cfg4_edge_messages_per_s_nominal"] > 0
     four = [c for c in cfg["configs"] if c["config"] == 4][0]
     assert len(four["per_rank_step_ms"]) == 2 and "GradientReducer" in four["gradient_allreduce"]
+    # the record says what ran the collectives and on how many different devices (never a gloo number read as xGMI)
+    two_gpus = torch.cuda.device_count() >= 2
+    assert cfg["collective_backend"] == ("nccl" if two_gpus else "gloo") == cfg["cfg4_collective_backend"]
+    assert cfg["ranks_distinct_devices"] == (2 if two_gpus else 1)
+    assert cfg["cfg4_step_modes_agree"] is True and cfg["cfg4_step_mode"] in ("phased", "after")
+    assert "[bench rank 0" in run.stderr and "[bench rank 1" in run.stderr          # per-phase progress of every rank

@@ -382,3 +382,6 @@ def test_multi_graph_graphed_steps_on_two_ranks_that_draw_different_graphs():
         assert rep["warm_launches"] == rep["buckets"], rep                  # constructor: one warm round only
         assert rep["per_step"] == [rep["buckets"]] * len(rep["per_step"]), rep
         assert rep["graphed_equals_eager"] and rep["losses_equal"] and rep["ranks_hold_equal_parameters"] and rep["finite"], rep
+        # what ran the collectives: on a node with two GPUs this IS RCCL on two different devices (the first such run must say so)
+        assert rep["backend"] == backend and rep["distinct_devices"] == (2 if backend == "nccl" else 1), rep
+        assert len(set(rep["modes"].values())) == 1 and rep["modes"] == reports[0]["modes"], rep

@@ -546,3 +546,37 @@ def test_grouped_relation_projection_backward_matches_autograd_of_the_reference_
                 assert d_w[l][k] is None or not d_w[l][k].any(), (l, name)
             else:
                 close(d_w[l][k], d_w64[l][k], (l, name))
+
+
+def test_sparse_first_layer_refuses_a_row_list_that_cannot_hold_every_slot():
+    """``ultra_first_layer_sparse_f32`` used to accept any ``row_list_len >= n_query``; rows whose slot did not fit kept
+    their raw sums with no epilogue and the call returned ULTRA_OK.  The caller now states ``max_runs`` and a shorter list is
+    ULTRA_ERR_BAD_SHAPE."""
+    import ultra_torchdrug_amd as U
+    from ultra_torchdrug_amd import RelCSR
+    dev = _dev()
+    n, r, Q = 300, 6, 4
+    g = random_graph(seed=4, n_node=n, n_edge=4000, n_rel=r)
+    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), None, n, n, r)
+    lib = U.require_library()
+    src_ptr, fwd_rank = csr.frontier_index
+    run_prefix, max_runs = csr.frontier_runs
+    relation = torch.randn(r, Q * 64, device=dev)
+    node = torch.tensor([1, 2, 3, 4], dtype=torch.int32, device=dev)
+    value = torch.randn(Q, 64, device=dev)
+    weight, bias = torch.randn(64, 128, device=dev), torch.randn(64, device=dev)
+    out = torch.empty(n, Q, 64, device=dev)
+    offsets = torch.empty(Q + 1, dtype=torch.int32, device=dev)
+
+    def call(list_len):
+        row_list = torch.empty(max(list_len, 1), dtype=torch.int32, device=dev)
+        return lib.ultra_first_layer_sparse_f32(
+            csr.by_src.pointer, src_ptr.data_ptr(), fwd_rank.data_ptr(), run_prefix.data_ptr(), relation.data_ptr(), node.data_ptr(),
+            value.data_ptr(), Q, weight.data_ptr(), bias.data_ptr(), None, None, 1e-5, 1, 0, out.data_ptr(), row_list.data_ptr(),
+            list_len, max_runs, offsets.data_ptr(), n, r, torch.cuda.current_stream().cuda_stream)
+
+    assert max_runs > 1
+    if lib.ultra_first_layer_sparse_supported(n, r, Q):
+        assert call(Q * (max_runs + 1)) == 0
+        assert call(Q * (max_runs + 1) - 1) == 2 and call(Q) == 2          # ULTRA_ERR_BAD_SHAPE
+    torch.cuda.synchronize()

@@ -52,6 +52,7 @@ EXPORTS = (
     "ultra_rspmm_event_destroy",
     "ultra_rspmm_event_elapsed_ms",
     "ultra_rspmm_force_general_path",
+    "ultra_rspmm_reserve_cus",
     "ultra_rspmm_workspace_bytes",
     "ultra_rspmm_forward_f32",
     "ultra_rspmm_fwd_f32",
@@ -144,6 +145,8 @@ def load():
     lib.ultra_rspmm_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.ultra_rspmm_force_general_path.restype = i32
     lib.ultra_rspmm_force_general_path.argtypes = [i32]
+    lib.ultra_rspmm_reserve_cus.restype = i32
+    lib.ultra_rspmm_reserve_cus.argtypes = [i32]
     lib.ultra_rspmm_workspace_bytes.restype = sz
     lib.ultra_rspmm_workspace_bytes.argtypes = [seg, i64]
     lib.ultra_rspmm_forward_f32.restype = i32
@@ -161,8 +164,8 @@ def load():
     lib.ultra_first_layer_sparse_supported.restype = i32
     lib.ultra_first_layer_sparse_supported.argtypes = [i64, i64, i64]
     lib.ultra_first_layer_sparse_f32.restype = i32
-    lib.ultra_first_layer_sparse_f32.argtypes = [seg, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, i64, vp,
-                                                 i64, i64, vp]
+    lib.ultra_first_layer_sparse_f32.argtypes = [seg, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, i64, i64,
+                                                 vp, i64, i64, vp]
     lib.ultra_rspmm_backward_f32.restype = i32
     lib.ultra_rspmm_backward_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, i32, i32, vp]
     lib.ultra_rspmm_backward_accumulate_f32.restype = i32

@@ -975,11 +975,13 @@ constexpr int kQuadUX = ULTRA_QUAD_UX;   // ... with the gathered matrix in LDS
 
 struct DeviceInfo {
     bool valid = false;
-    int n_cu = 0;
+    int n_cu = 0;            // compute units the persistent grids are sized for (= n_cu_total - ultra_rspmm_reserve_cus)
+    int n_cu_total = 0;
     int lds_bytes = 0;
     char arch[64] = {0};
 };
 DeviceInfo g_dev[16];
+int g_reserve_cus = 0;       // ultra_rspmm_reserve_cus
 
 int device_info(int device, DeviceInfo **out) {
     if (device < 0 || device >= 16) return ULTRA_ERR_NO_DEVICE;
@@ -987,7 +989,8 @@ int device_info(int device, DeviceInfo **out) {
     if (!d.valid) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
-        d.n_cu = prop.multiProcessorCount;
+        d.n_cu_total = prop.multiProcessorCount;
+        d.n_cu = std::max(kXcd, d.n_cu_total - g_reserve_cus);
         d.lds_bytes = (int)prop.maxSharedMemoryPerMultiProcessor;
         std::strncpy(d.arch, prop.gcnArchName, sizeof(d.arch) - 1);
         d.valid = true;
@@ -1525,11 +1528,19 @@ const char *ultra_rspmm_status_string(int status) {
 
 int ultra_rspmm_last_hip_error(void) { return ultra_detail_last_hip_error; }
 
+int ultra_rspmm_reserve_cus(int n) {
+    if (n < 0) return ULTRA_ERR_BAD_SHAPE;
+    g_reserve_cus = n;
+    for (DeviceInfo &d : g_dev)
+        if (d.valid) d.n_cu = std::max(kXcd, d.n_cu_total - n);
+    return ULTRA_OK;
+}
+
 int ultra_rspmm_device_info(int device, int *n_cu, int *lds_bytes, char *arch_host, size_t arch_len) {
     DeviceInfo *di = nullptr;
     int rc = device_info(device, &di);
     if (rc) return rc;
-    if (n_cu) *n_cu = di->n_cu;
+    if (n_cu) *n_cu = di->n_cu_total;
     if (lds_bytes) *lds_bytes = di->lds_bytes;
     if (arch_host && arch_len > 0) {
         std::strncpy(arch_host, di->arch, arch_len - 1);
@@ -1731,12 +1742,14 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
                                  const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
                                  const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
                                  const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                                 float *out, int32_t *row_list, int64_t row_list_len, int32_t *list_offset, int64_t n_dst,
-                                 int64_t n_rel, void *stream) {
+                                 float *out, int32_t *row_list, int64_t row_list_len, int64_t max_runs, int32_t *list_offset,
+                                 int64_t n_dst, int64_t n_rel, void *stream) {
     int rc = check_segments(by_src);
     if (rc) return rc;
-    if (!ultra_first_layer_sparse_supported(n_dst, n_rel, n_query) || by_src->piece_len <= 0 || row_list_len < n_query ||
-        row_list_len > 0x7fffffffLL)
+    // a list that cannot hold every query's slots (one per (source, destination) run of its boundary node + its own row) would
+    // leave rows with their raw sums and no epilogue, silently: refused here
+    if (!ultra_first_layer_sparse_supported(n_dst, n_rel, n_query) || by_src->piece_len <= 0 || max_runs < 0 ||
+        max_runs > n_dst || row_list_len < n_query * (max_runs + 1) || row_list_len > 0x7fffffffLL)
         return ULTRA_ERR_BAD_SHAPE;
     if (src_ptr == nullptr || fwd_rank == nullptr || run_prefix == nullptr || relation == nullptr || boundary_node == nullptr ||
         boundary_value == nullptr || weight == nullptr || bias == nullptr || out == nullptr || row_list == nullptr ||

@@ -294,8 +294,13 @@ class GraphedTrainStep:
 
         with reducer.paused():
             with torch.cuda.graph(graphs[0], capture_error_mode="relaxed"):
-                self.static_loss, self.static_metric = task(self.static_batch)
-                cuts, rel_inputs = model.last_cuts, task.last_relation_inputs
+                model.record_cuts = task.record_cuts = True         # only this forward records the cut tensors
+                try:
+                    self.static_loss, self.static_metric = task(self.static_batch)
+                    cuts, rel_inputs = model.last_cuts, task.last_relation_inputs
+                finally:
+                    model.record_cuts = task.record_cuts = False
+                    model.last_cuts = task.last_relation_inputs = None
                 self.last_negatives = task.last_negatives   # (B, num_negative): the tensor every replay rewrites
                 if cuts is not None and rel_inputs:
                     got = torch.autograd.grad(self.static_loss, params[0] + cuts, allow_unused=True)
@@ -483,8 +488,17 @@ class GraphedMultiGraphTrainStep:
         if step is not None:
             step.communicate = self.communicate
         if step is None or len(triples) != self.batch_size:          # ragged batch / tiny graph: the eager step
-            return train_step(self.task, self.optimizer, (triples, graph_id), reducer=self.reducer)
+            # (honours `communicate` too: a no-traffic measurement must not contain an eager step's collectives, and a rank on
+            # the eager branch must issue what its replaying peers issue -- ADVICE r4)
+            return train_step(self.task, self.optimizer, (triples, graph_id), reducer=self.reducer, communicate=self.communicate)
         return step(triples)
+
+    @property
+    def modes(self):
+        """``{graph_id: mode}`` of the captured steps ("phased" / "after" / "in_graph" / "single"): a capture whose phased
+        backward does not verify bit for bit falls back to "after" with a warning, possibly on one rank and not another --
+        the collective sequences still match, the overlap is lost there.  bench.py prints this and flags disagreement."""
+        return {name: step.mode for name, step in self.steps.items()}
 
 
 class GraphedScores:
@@ -996,17 +1010,22 @@ def reduce_metrics(metric):
     return {k: packed[i] for i, k in enumerate(keys)}
 
 
-def train_step(task, optimizer, batch, reducer=None):
+def train_step(task, optimizer, batch, reducer=None, communicate=True):
     """One fine-tuning step (``ultra/engine.py:62-92`` / torchdrug ``Engine.train``): forward, backward,
     gradient all-reduce, optimizer step.  Returns (loss, metrics averaged over ranks).  ``reducer``: a
     :class:`GradientReducer` over ``task`` -- its hooks start each layer's all-reduce on a side stream while backward
-    is still running; without one the gradients go through one flat blocking all-reduce after backward."""
+    is still running; without one the gradients go through one flat blocking all-reduce after backward.
+    ``communicate=False`` (timing only: what the collectives cost): no cross-rank traffic at all -- the backward runs with the
+    reducer's hooks paused, no gradient and no metric reduce."""
+    import contextlib
     loss, metric = task(batch)
     optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    if reducer is not None:
-        reducer.finish()
-    else:
-        allreduce_gradients(task)
+    with (reducer.paused() if (reducer is not None and not communicate) else contextlib.nullcontext()):
+        loss.backward()
+    if communicate:
+        if reducer is not None:
+            reducer.finish()
+        else:
+            allreduce_gradients(task)
     optimizer.step()
-    return loss.detach(), reduce_metrics(metric)
+    return loss.detach(), (reduce_metrics(metric) if communicate else metric)

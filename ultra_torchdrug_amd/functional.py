@@ -257,7 +257,7 @@ def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, l
             b_node.data_ptr(), b_value.data_ptr(), n_query, weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
             ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
             ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
-            out.data_ptr(), row_list.data_ptr(), row_list.numel(), list_offset.data_ptr(), n_dst, n_rel, _stream()))
+            out.data_ptr(), row_list.data_ptr(), row_list.numel(), int(max_runs), list_offset.data_ptr(), n_dst, n_rel, _stream()))
     return out
 
 

@@ -25,6 +25,10 @@ class TransferNBFNet(nn.Module):
     # and phased captured steps sum the query gradient in the SAME association and stay bit-identical; None switches it off.
     cut_after = "auto"
     last_cuts = None
+    # `last_cuts` is written only while this is set (engine.GraphedTrainStep._capture_phased sets it around its forward): the
+    # list holds a full (N, B, 64) activation, the late relation tables and their autograd chains, and the module would keep
+    # them alive through the rest of the backward and the optimizer step of every ordinary training step
+    record_cuts = False
 
     def cut_at(self):
         if self.cut_after == "auto":
@@ -159,7 +163,7 @@ class TransferNBFNet(nn.Module):
             last_rows = backend.get().candidate_rows(grad_candidates, graph.num_node)
         for position, conv in enumerate(self.layers):
             step_graph = graph if (cut is None or position < cut) else late_graph
-            if cut is not None and position == cut:
+            if cut is not None and position == cut and self.record_cuts:
                 self.last_cuts = ([layer_input] + [late_graph.relation_tables[id(c)] for c in list(self.layers)[cut:]]
                                   + [query_late])
             if separate_grad:
@@ -308,6 +312,19 @@ class TransferNBFNet(nn.Module):
         every row of the corrupted side lists ALL entities in order (full-batch evaluation, task.py:249-259); the
         tail gather is then the identity and the score head runs as one fused kernel."""
         keep, removal = None, None
+        if self.check_indices and r_index is not None:
+            # BEFORE anything consumes the ids (edge removal, negative flip, the fused kernels index with them without a bounds
+            # check of their own -- frontier: src_ptr[h]; candidate tiles: an LDS bitmap at (t, b); score rows: hidden[t, b]): an id
+            # from another split's vocabulary fails in an ATen index kernel in the reference and must fail HERE, not corrupt
+            # memory (ADVICE r3 / r4); one stacked host read; captured steps validate their batches once instead
+            # (engine.validate_triples).  Relation ids are checked against the graph's own vocabulary, before inverses double it.
+            n_node, n_rel = graph.num_node, max(graph.num_relation, 1)
+            bad = ((h_index < 0) | (h_index >= n_node) | (t_index < 0) | (t_index >= n_node)
+                   | (r_index < 0) | (r_index >= n_rel)).any()
+            if bool(bad):
+                raise IndexError("entity ids must lie in [0, %d) and relation ids in [0, %d): got h in [%d, %d], t in [%d, %d], "
+                                 "r in [%d, %d]" % (n_node, n_rel, int(h_index.min()), int(h_index.max()), int(t_index.min()),
+                                                    int(t_index.max()), int(r_index.min()), int(r_index.max())))
         if all_loss is not None:
             # training: the batch's own positive edges must not carry messages (model.py:146-147).  The reference
             # builds (and torchdrug re-sorts) a new graph every step; here the cached plans of the full graph are
@@ -352,20 +369,9 @@ class TransferNBFNet(nn.Module):
             t_index = t_index.view(-1, 1)
             r_index = torch.zeros_like(h_index)
 
-        if self.check_indices:      # two host syncs per call (model.py:174-175); engine.GraphedPredict turns them
-            assert (h_index[:, [0]] == h_index).all()       # off while a hipGraph is captured / replayed
-            assert (r_index[:, [0]] == r_index).all()
-            # the fused kernels index with these ids without a bounds check of their own (frontier: src_ptr[h]; candidate
-            # tiles: an LDS bitmap at (t, b); score rows: hidden[t, b] read, d_hidden[t, b] written): an id from another
-            # split's vocabulary fails in an ATen index kernel in the reference and must fail HERE, not corrupt memory
-            # (ADVICE r3); captured steps validate their batches once instead (engine.validate_triples)
-            n_node, n_rel = graph.num_node, max(graph.num_relation, 1)
-            bad = ((h_index < 0) | (h_index >= n_node) | (t_index < 0) | (t_index >= n_node)
-                   | (r_index < 0) | (r_index >= n_rel)).any()
-            if bool(bad):
-                raise IndexError("entity ids must lie in [0, %d) and relation ids in [0, %d): got h in [%d, %d], t in [%d, %d], "
-                                 "r in [%d, %d]" % (n_node, n_rel, int(h_index.min()), int(h_index.max()), int(t_index.min()),
-                                                    int(t_index.max()), int(r_index.min()), int(r_index.max())))
+        if self.check_indices:      # the reference's consistency asserts (model.py:174-175) as ONE host read; engine.GraphedPredict
+            # turns them off while a hipGraph is captured / replayed
+            assert bool(((h_index[:, [0]] == h_index).all() & (r_index[:, [0]] == r_index).all()))
         if all_entities and self._fused_score_ok(graph, t_index, metric):
             parts = self.bellmanford(graph, h_index[:, 0], r_index[:, 0], want_feature=False)
             first, second = self.mlp.layers

@@ -295,7 +295,8 @@ class KnowledgeGraphCompletion(nn.Module):
         pos_h_index, pos_t_index, pos_r_index = batch.t()
         batch_size = len(batch)
         rel_inputs = self.relation_representations(pos_r_index, all_loss, metric)
-        self.last_relation_inputs = rel_inputs if all_loss is not None else None     # (a phased backward resumes from these)
+        # (a phased backward resumes from these; kept only while engine.GraphedTrainStep._capture_phased asks for them)
+        self.last_relation_inputs = rel_inputs if (all_loss is not None and getattr(self, "record_cuts", False)) else None
 
         if all_loss is None and self.full_batch_eval and self.fuse_sides:         # evaluation, both sides at once
             # rows 0..B-1: (h, r, ?);  rows B..2B-1: (?, r, t) in tail form = (t, r + R, ?)  (model.py:76-83)
