@@ -587,6 +587,22 @@ size_t ultra_relcsr_dense_bytes(int64_t n_rows, int64_t n_cols, int kind);
 int ultra_relcsr_dense(const ultra_segments *plan, int64_t n_rows, int64_t n_cols, int kind, uint32_t *dense, void *stream);
 
 /*
+ * One whole layer of the relation-graph Bellman-Ford in inference on a plan that carries its dense form (ABI 7):
+ *     out = [input +] relu(LayerNorm(Linear_{128->64}(cat[input, rspmm_{add,mul}(input) + boundary])))
+ * = GeneralizedRelationalConvNBF.forward (/root/reference/ultra/layer.py:111-190) + the shortcut of ultra/rel_model.py:371-372
+ * -- ultra_rspmm_forward_boundary_f32 followed by ultra_combine_forward_f32, bit for bit, in one launch: the workgroup that sums
+ * 16 nodes x one query's 64 columns holds 16 complete rows of the epilogue and finishes them on the same matrix cores.
+ *   input [n, n_query, 64] (also the gathered matrix [n, n_query * 64]);  relation [4, n_query * 64];  out [n, n_query, 64],
+ *   not aliasing input;  boundary as in ultra_rspmm_forward_boundary_f32 with block = 64;  weight [64, 128].
+ * ultra_dense_layer_supported: 1 where the entry applies (dense form present, square adjacency, sizes within 32-bit offsets).
+ */
+int ultra_dense_layer_supported(const ultra_segments *fwd, int64_t n_query);
+int ultra_dense_layer_forward_f32(const ultra_segments *fwd, const float *relation, const float *input,
+                                  const int32_t *boundary_node, const float *boundary_value, int64_t n_query, const float *weight,
+                                  const float *bias, const float *ln_weight, const float *ln_bias, float ln_eps, int relu,
+                                  int shortcut, float *out, void *stream);
+
+/*
  * On-box calibration for the HBM roofline line of bench.py ("confirm on the box with a copy / gather
  * calibration, report both"): the bare gather of `n_index` random 256-byte rows of `table` (n_rows x 64 fp32) -- four rows
  * per wave-instruction (buffer_load_dwordx4), eight instructions in flight per wave, every lane's values summed into

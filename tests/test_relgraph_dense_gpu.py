@@ -206,3 +206,27 @@ def test_first_layer_frontier_on_a_dense_graph_sums_without_pieces(oracle):
     assert np.array_equal(got.cpu().numpy(), want)
     full = UF.rspmm_forward(csr, _t(relation), _t(dense_b), "add", "mul", boundary=(_t(node), _t(value)))
     assert torch.equal(got, full)
+
+
+@pytest.mark.parametrize("n,density,q", [(90, 1.0, 3), (120, 0.5, 16), (474, 1.0, 16), (70, 0.3, 1)])
+@pytest.mark.parametrize("norm,relu,shortcut", [(True, True, True), (False, True, False), (True, False, True)])
+def test_fused_dense_layer_equals_rspmm_plus_epilogue(n, density, q, norm, relu, shortcut):
+    """ultra_dense_layer_forward_f32 (a whole relation-graph layer in one launch) == the dense rspmm with the sparse boundary
+    followed by the fused epilogue kernel, bit for bit (which the other tests of this file and test_model_gpu hold to the oracle)."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = _dev()
+    g = _graph(21, n, density)
+    csr = _relcsr(g, n)
+    gen = torch.Generator(device=dev).manual_seed(n + q)
+    hidden = torch.randn(n, q, 64, device=dev, generator=gen)
+    relation = torch.randn(4, q * 64, device=dev, generator=gen)
+    node = torch.randint(0, n, (q,), device=dev, generator=gen).to(torch.int32)
+    value = torch.randn(q, 64, device=dev, generator=gen)
+    weight, bias = torch.randn(64, 128, device=dev, generator=gen) * 0.2, torch.randn(64, device=dev, generator=gen)
+    ln = (torch.rand(64, device=dev, generator=gen) + 0.5, torch.randn(64, device=dev, generator=gen)) if norm else (None, None)
+    args = (weight, bias, ln[0], ln[1], 1e-5, relu, shortcut)
+    update = UF.rspmm_forward(csr, relation, hidden.flatten(1), "add", "mul", boundary=(node, value))
+    want = UF.combine_forward(hidden, update.view(n, q, 64), *args)
+    got = UF.dense_layer_forward(csr, relation, hidden, (node, value), *args)
+    assert got is not None and got.data_ptr() != hidden.data_ptr()
+    assert torch.equal(got, want), "fused layer differs by %.3g" % (got - want).abs().max().item()

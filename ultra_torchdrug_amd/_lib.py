@@ -99,6 +99,8 @@ EXPORTS = (
     "ultra_relcsr_dense_bytes",
     "ultra_relcsr_dense",
     "ultra_calibrate_gather_f32",
+    "ultra_dense_layer_supported",
+    "ultra_dense_layer_forward_f32",
 )
 
 _lib = None
@@ -242,6 +244,10 @@ def load():
     lib.ultra_relcsr_dense_bytes.argtypes = [i64, i64, i32]
     lib.ultra_relcsr_dense.restype = i32
     lib.ultra_relcsr_dense.argtypes = [seg, i64, i64, i32, vp, vp]
+    lib.ultra_dense_layer_supported.restype = i32
+    lib.ultra_dense_layer_supported.argtypes = [seg, i64]
+    lib.ultra_dense_layer_forward_f32.restype = i32
+    lib.ultra_dense_layer_forward_f32.argtypes = [seg, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp]
     lib.ultra_calibrate_gather_f32.restype = i32
     lib.ultra_calibrate_gather_f32.argtypes = [vp, i64, vp, i64, vp, ctypes.POINTER(i64), vp]
     if lib.ultra_rspmm_abi_version() != ABI_VERSION:

@@ -106,10 +106,7 @@ __device__ __forceinline__ float entry(uint32_t word) {
 // matrix is one byte per entry, a lane's entries for four consecutive sources in one word: 0.5 vector-memory instructions per
 // MFMA instead of 2.
 template <int MUL, bool HAS_REL>
-__global__ __launch_bounds__(kDnWaves * 64) void dense_rows_kernel(const DenseParams p) {
-    int vt, ct;
-    if (!dense_item(p, vt, ct)) return;
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ dn4 dense_rows_sum(const DenseParams &p, const int vt, const int ct, const int lane) {
     const int i = lane & 15, kq = lane >> 4;
     const long long F = p.F;
     const int col = ct * 16 + i;
@@ -184,6 +181,18 @@ __global__ __launch_bounds__(kDnWaves * 64) void dense_rows_kernel(const DensePa
         c0[0] = a0[0]; c0[1] = a0[1];
         compute(s1, c1);                      // block t + 1
     }
+    return acc;
+}
+
+template <int MUL, bool HAS_REL>
+__global__ __launch_bounds__(kDnWaves * 64) void dense_rows_kernel(const DenseParams p) {
+    int vt, ct;
+    if (!dense_item(p, vt, ct)) return;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const long long F = p.F;
+    const int col = ct * 16 + i;
+    const dn4 acc = dense_rows_sum<MUL, HAS_REL>(p, vt, ct, lane);
 
     // acc[r] = D[row 4 kq + r][column i]; the epilogue the reference applies right after the call (layer.py:156,358)
     int b_node = -1;
@@ -202,6 +211,102 @@ __global__ __launch_bounds__(kDnWaves * 64) void dense_rows_kernel(const DensePa
             p.out[(long long)row * F + col] = v;
         }
     }
+}
+
+// The WHOLE layer of a relation-graph Bellman-Ford in inference, one launch:
+//     out = [input +] relu(LayerNorm(Linear_{128->64}(cat[input, rspmm(input) + boundary])))
+// = GeneralizedRelationalConvNBF.forward (/root/reference/ultra/layer.py:111-190) + the caller's shortcut
+// (ultra/rel_model.py:371-372).  A workgroup's four waves hold the sums of 16 nodes x the 64 columns of ONE query -- 16 complete
+// rows of the epilogue -- so the 128 -> 64 product follows on the same matrix cores without the rows leaving the chip: wave w
+// computes outputs 16 w .. 16 w + 15 with K = 4 per instruction = (in[s], up[s], in[s+1], up[s+1]), i.e. the fmaf chain
+// bias, in[0], up[0], in[1], up[1], ... of combine_kernel / oracle_combine_forward; LayerNorm as two sequential 32-column half
+// sums added once, relu, shortcut: the same expressions.  Bit-identical to dense_rows_kernel + combine_kernel
+// (tests/test_relgraph_dense_gpu.py), one launch and one (N, Q, 64) round trip through memory less per layer.
+struct DenseLayerParams {
+    DenseParams d;           // the sums (d.out unused); d.gather is also the layer's `input` [n_rows, Q, 64]
+    const float *weight;     // [64, 128]
+    const float *bias, *gamma, *beta;
+    float eps;
+    int relu, shortcut;
+    float *out;              // [n_rows, Q, 64], must not alias the input (other workgroups still gather from it)
+};
+constexpr int kDlStride = 68;        // floats per staged row: 16-byte aligned, rows 4 banks apart
+
+__global__ __launch_bounds__(kDnWaves * 64) void dense_layer_kernel(const DenseLayerParams q) {
+    const DenseParams &p = q.d;
+    __shared__ __attribute__((aligned(16))) float t_in[16 * kDlStride], t_up[16 * kDlStride], t_z[16 * kDlStride];
+    int vt, ct;
+    if (!dense_item(p, vt, ct)) return;          // F % 64 == 0: a workgroup's four waves all have a tile or none has
+    const int lane = threadIdx.x & 63, wave = ct & 3;
+    const int i = lane & 15, kq = lane >> 4;
+    const long long F = p.F;
+    const int col = ct * 16 + i;
+    // B fragments of the epilogue, requested before the walk: lane (i, kq) feeds W[16 w + i][64 (kq & 1) + (kq >> 1) + 2 j]
+    float wf[32];
+    {
+        const float *wrow = q.weight + (long long)(16 * wave + i) * 128 + 64 * (kq & 1) + (kq >> 1);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wf[j] = wrow[2 * j];
+    }
+    const float bias = q.bias[16 * wave + i];
+    // the layer's input rows of this tile (rows 4 w .. 4 w + 3 by this wave: four 256-byte rows per load)
+    {
+        const int row = vt * 16 + 4 * wave + kq;
+        dn4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (row < p.n_rows) v = *reinterpret_cast<const dn4 *>(p.gather + (long long)row * F + (ct & ~3) * 16 + 4 * i);
+        *reinterpret_cast<dn4 *>(t_in + (4 * wave + kq) * kDlStride + 4 * i) = v;
+    }
+    const dn4 acc = dense_rows_sum<ULTRA_MUL_MUL, true>(p, vt, ct, lane);
+    {
+        const int b_node = p.bnode[col / 64];
+        const float b_val = p.bvec[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = vt * 16 + 4 * kq + r;
+            t_up[(4 * kq + r) * kDlStride + 16 * wave + i] = acc[r] + (row == b_node ? b_val : 0.0f);
+        }
+    }
+    __syncthreads();
+    dn4 z = {bias, bias, bias, bias};
+    {
+        const float *src = ((kq & 1) ? t_up : t_in) + i * kDlStride + (kq >> 1);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z = __builtin_amdgcn_mfma_f32_16x16x4f32(src[2 * j], wf[j], z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t_z[(4 * kq + r) * kDlStride + 16 * wave + i] = z[r];
+    __syncthreads();
+    // LayerNorm, relu, shortcut: wave w finishes rows 4 w .. 4 w + 3, 16 lanes x 4 columns per row; the two half sums of a row are
+    // taken SEQUENTIALLY (columns 0..31, 32..63) by the row's lanes 0 and 8 and handed to the others
+    const int lrow = 4 * wave + kq;
+    const float *zr = t_z + lrow * kDlStride;
+    dn4 v = *reinterpret_cast<const dn4 *>(zr + 4 * i);
+    if (q.gamma != nullptr) {
+        const int half = (i >> 3) & 1;
+        float s = 0.0f;
+        if ((i & 7) == 0)
+            for (int c = 0; c < 32; ++c) s = s + zr[32 * half + c];
+        const float s0 = __shfl(s, 16 * kq, 64), s1 = __shfl(s, 16 * kq + 8, 64);
+        const float mean = (s0 + s1) * (1.0f / 64.0f);
+        float ss = 0.0f;
+        if ((i & 7) == 0)
+            for (int c = 0; c < 32; ++c) { const float dlt = zr[32 * half + c] - mean; ss = ss + dlt * dlt; }
+        const float q0 = __shfl(ss, 16 * kq, 64), q1 = __shfl(ss, 16 * kq + 8, 64);
+        const float var = (q0 + q1) * (1.0f / 64.0f);
+        const float inv = 1.0f / sqrtf(var + q.eps);
+        const dn4 g = *reinterpret_cast<const dn4 *>(q.gamma + 4 * i), b = *reinterpret_cast<const dn4 *>(q.beta + 4 * i);
+        v.x = ((v.x - mean) * inv) * g.x + b.x; v.y = ((v.y - mean) * inv) * g.y + b.y;
+        v.z = ((v.z - mean) * inv) * g.z + b.z; v.w = ((v.w - mean) * inv) * g.w + b.w;
+    }
+    if (q.relu) {
+        v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f;
+    }
+    if (q.shortcut) {
+        const dn4 x = *reinterpret_cast<const dn4 *>(t_in + lrow * kDlStride + 4 * i);
+        v.x = v.x + x.x; v.y = v.y + x.y; v.z = v.z + x.z; v.w = v.w + x.w;
+    }
+    const int row = vt * 16 + lrow;
+    if (row < p.n_rows) *reinterpret_cast<dn4 *>(q.out + (long long)row * F + (ct & ~3) * 16 + 4 * i) = v;
 }
 
 // d_relation, first pass: tile sums T[tile][type][column] (order: include/ultra_rspmm.h).  K = 4 consecutive sources: the B
@@ -287,7 +392,15 @@ __global__ __launch_bounds__(256) void dense_drel_reduce_kernel(const float *til
     if (idx >= 4 * F) return;
     const long long t = idx / F, c = idx - t * F;
     float acc = 0.0f;
-    for (int vt = 0; vt < n_vt; ++vt) acc = acc + tiles[((long long)vt * 4 + t) * F + c];
+    // 16 tile sums in flight, added in tile order (one dependent load per tile made this 10 us for 30 tiles)
+    for (int v0 = 0; v0 < n_vt; v0 += 16) {
+        float part[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) part[j] = tiles[((long long)min(v0 + j, n_vt - 1) * 4 + t) * F + c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (v0 + j < n_vt) acc = acc + part[j];
+    }
     d_relation[idx] = acc;
 }
 
@@ -454,6 +567,40 @@ int ultra_relcsr_dense(const ultra_segments *plan, int64_t n_rows, int64_t n_col
                            dense_cols_pad(n_cols, kind), reinterpret_cast<uint8_t *>(dense), plan->rel);
         HIP_TRY(hipGetLastError());
     }
+    return ULTRA_OK;
+}
+
+int ultra_dense_layer_supported(const ultra_segments *fwd, int64_t n_query) {
+    if (fwd == nullptr || fwd->dense == nullptr || fwd->weight != nullptr || n_query <= 0) return 0;
+    if (fwd->dense_rows != fwd->n_rows || fwd->dense_rows != fwd->dense_cols) return 0;        // a layer maps the nodes onto themselves
+    const long long F = n_query * 64;
+    return (F * 4 < (1LL << 24) && fwd->dense_cols * F * 4 < (1LL << 31)) ? 1 : 0;
+}
+
+int ultra_dense_layer_forward_f32(const ultra_segments *fwd, const float *relation, const float *input,
+                                  const int32_t *boundary_node, const float *boundary_value, int64_t n_query, const float *weight,
+                                  const float *bias, const float *ln_weight, const float *ln_bias, float ln_eps, int relu,
+                                  int shortcut, float *out, void *stream) {
+    if (!ultra_dense_layer_supported(fwd, n_query)) return ULTRA_ERR_BAD_SHAPE;
+    if (relation == nullptr || input == nullptr || boundary_node == nullptr || boundary_value == nullptr || weight == nullptr ||
+        bias == nullptr || out == nullptr)
+        return ULTRA_ERR_NULL_POINTER;
+    if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (out == input) return ULTRA_ERR_BAD_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(input) | reinterpret_cast<uintptr_t>(ln_weight) |
+         reinterpret_cast<uintptr_t>(ln_bias)) & 15u)
+        return ULTRA_ERR_BAD_SHAPE;
+    DenseLayerParams q{};
+    DenseParams &d = q.d;
+    const long long F = n_query * 64;
+    d.adj = fwd->dense; d.relation = relation; d.gather = input; d.bnode = boundary_node; d.bvec = boundary_value; d.bdim = 64;
+    d.F = F; d.n_rows = (int)fwd->dense_rows; d.n_cols = (int)fwd->dense_cols; d.n_vt = (int)((fwd->dense_rows + 15) / 16);
+    d.n_ct = (int)(F / 16); d.cols_pad = dense_cols_pad(fwd->dense_cols, 0);
+    d.n_items = d.n_vt * (d.n_ct / kDnWaves); d.per_xcd = (d.n_items + kXcd - 1) / kXcd;
+    q.weight = weight; q.bias = bias; q.gamma = ln_weight; q.beta = ln_bias; q.eps = ln_eps; q.relu = relu; q.shortcut = shortcut;
+    q.out = out;
+    hipLaunchKernelGGL(dense_layer_kernel, dim3((unsigned)(d.per_xcd * kXcd)), dim3(kDnWaves * 64), 0, static_cast<hipStream_t>(stream), q);
+    HIP_TRY(hipGetLastError());
     return ULTRA_OK;
 }
 

@@ -21,7 +21,7 @@ import torch
 from . import _lib, _torch_ext
 from .relcsr import RelCSR
 
-__all__ = ["generalized_rspmm", "rspmm_forward", "first_layer_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "candidate_tiles", "candidate_rows", "score_candidates", "RelCSR"]
+__all__ = ["generalized_rspmm", "rspmm_forward", "first_layer_forward", "dense_layer_forward", "combine_forward", "combine", "linear_forward", "linear_supported", "score_all_entities", "relation_stack_inputs", "statistics", "bce_adversarial_loss", "candidate_tiles", "candidate_rows", "score_candidates", "RelCSR"]
 
 # Plans built from raw sparse tensors, most recent last.  Every entry holds strong references to the index and
 # value tensors it was built from, so a (data_ptr, version) key cannot be reused by another live tensor.
@@ -258,6 +258,47 @@ def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, l
             ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
             ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
             out.data_ptr(), row_list.data_ptr(), row_list.numel(), int(max_runs), list_offset.data_ptr(), n_dst, n_rel, _stream()))
+    return out
+
+
+# Relation-graph layers in inference as ONE launch where the plan carries its dense form (ultra_dense_layer_forward_f32).
+# ULTRA_DENSE_LAYER=0: the dense rspmm and the epilogue as two launches (same bits).
+DENSE_LAYER = __import__("os").environ.get("ULTRA_DENSE_LAYER", "1") != "0"
+
+
+def dense_layer_forward(csr, relation, input, boundary, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True,
+                        shortcut=False):
+    """One whole layer of a relation-graph Bellman-Ford in inference -- ``rspmm_forward(csr, relation, input.flatten(1), "add",
+    "mul", boundary=boundary)`` followed by ``combine_forward(input, update, ...)``, bit for bit -- in one launch, on a graph whose
+    plans carry their dense form (``/root/reference/ultra/layer.py:111-190``, ``ultra/rel_model.py:371-372``).  ``input``
+    ``(N, Q, 64)``; returns a new ``(N, Q, 64)`` tensor, or ``None`` where the entry does not apply (the caller runs the two calls)."""
+    if not DENSE_LAYER or not getattr(csr, "dense_form", False) or input.dim() != 3 or input.shape[-1] != 64:
+        return None
+    n, n_query = input.shape[0], input.shape[1]
+    F = n_query * 64
+    seg = csr.fwd
+    lib = _lib.load()
+    if seg.dense is None or csr.shape[0] != n or csr.shape[1] != n or csr.shape[2] != 4 or \
+            not lib.ultra_dense_layer_supported(seg.pointer, n_query):
+        return None
+    b_node, b_value = boundary
+    b_value = b_value.contiguous()
+    tensors = [relation, input, b_value, weight, bias] + ([ln_weight, ln_bias] if ln_weight is not None else [])
+    if (tuple(relation.shape) != (4, F) or tuple(b_value.shape) != (n_query, 64) or b_node.dtype != torch.int32
+            or not b_node.is_contiguous() or tuple(weight.shape) != (64, 128)
+            or any(t.dtype != torch.float32 or not t.is_cuda or t.device != input.device for t in tensors)
+            or b_node.device != input.device or csr.device != input.device):
+        raise RuntimeError("dense_layer_forward: input fp32 (N, Q, 64), relation fp32 (4, Q * 64), boundary (int32 (Q,), fp32 "
+                           "(Q, 64)), a (64, 128) weight, all on one HIP device")
+    relation, input = relation.contiguous(), input.contiguous()
+    out = torch.empty_like(input)
+    with torch.cuda.device(input.device):
+        _lib.check(lib.ultra_dense_layer_forward_f32(
+            seg.pointer, relation.data_ptr(), input.data_ptr(), b_node.data_ptr(), b_value.data_ptr(), n_query,
+            weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+            ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
+            ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
+            out.data_ptr(), _stream()))
     return out
 
 

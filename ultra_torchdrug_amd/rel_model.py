@@ -164,6 +164,11 @@ class CustomNBFNetFull(CustomNBFNet):
                 update = ops.rspmm_frontier(csr, tables[0], boundary).view(n_node, n_query, 64)
                 hidden = ops.combine_forward(None, update, *args, reuse_update=True, input_boundary=boundary)
             else:
+                # dense relation graphs: the layer as one launch on the matrix cores (csrc/relgraph_dense.hip); same bits
+                fused = ops.dense_layer_forward(csr, tables[i], hidden, boundary, *args)
+                if fused is not None:
+                    hidden = fused
+                    continue
                 update = ops.rspmm_forward(csr, tables[i], hidden.flatten(1), "add", "mul", boundary=boundary)
                 hidden = ops.combine_forward(hidden, update.view(n_node, n_query, 64), *args, reuse_update=True)
         return {"node_feature": hidden.transpose(1, 0)}
