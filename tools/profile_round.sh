@@ -15,28 +15,28 @@ PY=$(readlink -f "$(command -v python3)")     # the ELF interpreter itself: no s
 if ! head -c 4 "$PY" | grep -q ELF; then echo "python3 resolves to $PY, which is not an ELF binary" >&2; exit 1; fi
 out=gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/bench" -o bench -- "$PY" bench.py --steps 200 --warmup 20 > "$out/bench_under_rocprof.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/bench" -o bench -- "$PY" bench.py --steps 200 --warmup 20 > "$out/bench_under_rocprof.log" 2>&1
 grep "^{\"metric\"" "$out/bench_under_rocprof.log" | tail -1 > "$out/${tag}_bench_under_rocprof.json"
 find "$out/bench" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_bench_kernel_stats.csv" \;
 rm -rf "$out/bench"
 # fine-tuning steps (hipGraph replays) of the two fine-tuning shapes: per-kernel summary
 for wl in wn18rr fb15k237; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/train_$wl" -o train -- "$PY" tools/train_bench.py --workload S-$wl --graphed --steps 20 > "$out/train_$wl.log" 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/train_$wl" -o train -- "$PY" tools/train_bench.py --workload S-$wl --graphed --steps 20 > "$out/train_$wl.log" 2>&1
   find "$out/train_$wl" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_train_${wl}_kernel_stats.csv" \;
   grep -h "ms/step" "$out/train_$wl.log" > "$out/${tag}_train_${wl}_step.txt"
   rm -rf "$out/train_$wl"
 done
 # one evaluation batch replayed as a hipGraph, kernel by kernel (headline graph and the small config-2 graph)
 for wl in fb15k237 codexs; do
-  WORKLOAD=S-$wl rocprofv3 --kernel-trace --output-format csv -d "$out/step_$wl" -o st -- "$PY" tools/debug/step_trace.py > "$out/step_$wl.log" 2>&1
+  WORKLOAD=S-$wl timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$out/step_$wl" -o st -- "$PY" tools/debug/step_trace.py > "$out/step_$wl.log" 2>&1
   d=$(dirname "$(find "$out/step_$wl" -name "*kernel_trace.csv" | tail -1)")
   "$PY" tools/debug/step_trace_report.py "$d" > "$out/${tag}_step_trace_${wl}.txt" 2>&1
   rm -rf "$out/step_$wl"
 done
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --pmc $pass --output-format csv -d "$out/stress_$name" -- "$PY" tools/stress_bench.py --reps 2 --knob 0 > "$out/stress_$name.log" 2>&1
-  rocprofv3 --pmc $pass --output-format csv -d "$out/fwd_$name" -- "$PY" tools/kbench.py --workload S-fb15k237 --batch 32 --reps 4 > "$out/fwd_$name.log" 2>&1
+  timeout 300 rocprofv3 --pmc $pass --output-format csv -d "$out/stress_$name" -- "$PY" tools/stress_bench.py --reps 2 --knob 0 > "$out/stress_$name.log" 2>&1
+  timeout 300 rocprofv3 --pmc $pass --output-format csv -d "$out/fwd_$name" -- "$PY" tools/kbench.py --workload S-fb15k237 --batch 32 --reps 4 > "$out/fwd_$name.log" 2>&1
 done
 "$PY" - "$out" "$tag" <<'PY'
 import csv, glob, json, sys
