@@ -216,6 +216,35 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
                                  float *out, int32_t *row_list, int64_t row_list_len, int64_t max_runs, int32_t *list_offset,
                                  int64_t n_dst, int64_t n_rel, void *stream);
 
+/* The first layer of an entity Bellman-Ford in TRAINING, sparse end to end (ABI 7; csrc/first_layer_train.inc).  Forward:
+ * ultra_first_layer_sparse_f32 with the frontier's raw rows kept -- `update` [n_dst, n_query, 64] receives them at the LISTED rows
+ * (what the epilogue's backward recomputes from; every other row of `update` stays unwritten), `out` receives the constant row
+ * everywhere and the epilogue's result at the listed rows; row_list / list_offset as there (list_offset[n_query] = slots in use).
+ * Same bits in `out` as ultra_rspmm_frontier_f32 + ultra_combine_forward_boundary_f32.
+ * Backward of that layer's epilogue, ultra_first_layer_epilogue_backward_f32: the listed rows of input / update / grad_out are
+ * gathered into dense buffers, run through the one-pass backward of ultra_combine_backward_fused_f32 (which reads the row count
+ * from the device) and their d_input / d_update rows scattered back -- d_input [rows, 64] is zero elsewhere, d_update is written
+ * at the listed rows only (the first layer's rspmm backward reads it there only) -- and every other row's share of d_bias /
+ * d_ln_weight / d_ln_bias, a fixed linear map J(bias, LayerNorm, relu) of the COLUMN SUMS of grad_out over those rows, is added.
+ *   list_count : device pointer to the number of slots in use (list_offset + n_query);  list_cap: slots row_list holds
+ *   workspace  : ultra_first_layer_epilogue_backward_workspace(device, list_cap) bytes
+ * Gradients equal the dense backward's up to the association of the sums.  ultra_column_sum_f32: deterministic column sums of a
+ * (rows, 64) matrix (rows_dev: optional device-side row count; partial_workspace: ultra_column_sum_blocks() x 64 floats). */
+int ultra_first_layer_sparse_train_f32(const ultra_segments *by_src, const int32_t *src_ptr, const int32_t *fwd_rank,
+                                       const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
+                                       const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                                       const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                                       float *update, float *out, int32_t *row_list, int64_t row_list_len, int64_t max_runs,
+                                       int32_t *list_offset, int64_t n_dst, int64_t n_rel, void *stream);
+size_t ultra_first_layer_epilogue_backward_workspace(int device, int64_t list_cap);
+int ultra_first_layer_epilogue_backward_f32(const float *input, const float *update, const float *grad_out, const int32_t *row_list,
+                                            const int32_t *list_count, int64_t list_cap, const float *weight, const float *bias,
+                                            const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                                            float *d_input, float *d_update, float *d_weight, float *d_bias, float *d_ln_weight,
+                                            float *d_ln_bias, float *workspace, size_t workspace_bytes, int64_t rows, void *stream);
+int ultra_column_sum_blocks(void);
+int ultra_column_sum_f32(const float *x, int64_t rows, const int32_t *rows_dev, float *partial_workspace, float *out, void *stream);
+
 /* d_input of the FIRST layer's rspmm in training, at the rows that are used: that layer's input is the boundary
  * (/root/reference/ultra/model.py:106-107,116-120), whose gradient autograd consumes at row (boundary_node[q], query block q)
  * only.  For every query q:

@@ -588,6 +588,48 @@ def test_last_layer_backward_over_the_candidate_tiles_gives_the_gradients_of_all
         assert (grads[True][k] - grads[False][k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
 
 
+def test_sparse_first_layer_in_training_gives_the_gradients_of_the_dense_layer():
+    """Training, first entity layer (csrc/first_layer_train.inc): its input is the boundary, so a row no out-edge of the query's
+    boundary node reaches has a zero input row and a zero update row -- the forward broadcasts ONE constant row there (bits of the
+    dense layer: the loss must be identical), and the backward runs the one-pass epilogue backward on the listed rows' tiles only
+    and takes every other row's share of d_bias / d_gamma / d_beta from the column sums of the upstream gradient.  Every parameter
+    gradient of a whole step must agree with the dense first layer (fp32 tolerance: three 64-float sums in another association);
+    graphs with hub heads (most rows touched), isolated heads and removed (zero-weight) edges."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    old_rows, old_fraction = UF.SPARSE_FIRST_LAYER_MIN_ROWS, UF.SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION
+    UF.SPARSE_FIRST_LAYER_MIN_ROWS = 0                           # (the size / density rules would send these small graphs to the
+    UF.SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION = 1.0               #  dense form)
+    try:
+        for shape, seed in (((1200, 9000, 12), 5), ((5000, 20000, 7), 6)):
+            task, triples = _build(shape)
+            task.num_negative = 32
+            task.to(dev).train()
+            batch = torch.from_numpy(triples[:16]).to(dev)           # fact edges: removed from the step's graph (zero weights)
+            results = {}
+            for sparse in (True, False):
+                UF.SPARSE_FIRST_LAYER_TRAIN = sparse
+                try:
+                    task.zero_grad(set_to_none=True)
+                    torch.manual_seed(seed)
+                    loss, _ = task(batch)
+                    loss.backward()
+                    results[sparse] = (loss.detach().clone(),
+                                       {k: p.grad.detach().clone() for k, p in task.named_parameters() if p.grad is not None})
+                finally:
+                    UF.SPARSE_FIRST_LAYER_TRAIN = True
+            assert torch.equal(results[True][0], results[False][0]), "the sparse first layer changed the forward"
+            und = task.model._undirected(task.fact_graph)
+            assert 0.0 < und.relcsr.frontier_fraction < 1.0
+            g_s, g_d = results[True][1], results[False][1]
+            assert g_s.keys() == g_d.keys() and len(g_s) > 20
+            for k in g_s:
+                scale = g_d[k].abs().max().item()
+                assert (g_s[k] - g_d[k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
+    finally:
+        UF.SPARSE_FIRST_LAYER_MIN_ROWS, UF.SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION = old_rows, old_fraction
+
+
 def test_score_head_on_candidate_rows_matches_the_reference_chain():
     """ultra_score_rows_* (gather of the candidate rows, concatenation with the query, the 128 -> 128 -> 1 mlp, and the whole
     backward, as one autograd node) against index + cat + nn.Linear chain in fp64 (ultra/model.py:177-183,193): scores and

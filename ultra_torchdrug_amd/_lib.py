@@ -99,6 +99,11 @@ EXPORTS = (
     "ultra_relcsr_dense_bytes",
     "ultra_relcsr_dense",
     "ultra_calibrate_gather_f32",
+    "ultra_first_layer_sparse_train_f32",
+    "ultra_first_layer_epilogue_backward_workspace",
+    "ultra_first_layer_epilogue_backward_f32",
+    "ultra_column_sum_blocks",
+    "ultra_column_sum_f32",
     "ultra_dense_layer_supported",
     "ultra_dense_layer_forward_f32",
 )
@@ -244,6 +249,18 @@ def load():
     lib.ultra_relcsr_dense_bytes.argtypes = [i64, i64, i32]
     lib.ultra_relcsr_dense.restype = i32
     lib.ultra_relcsr_dense.argtypes = [seg, i64, i64, i32, vp, vp]
+    lib.ultra_first_layer_sparse_train_f32.restype = i32
+    lib.ultra_first_layer_sparse_train_f32.argtypes = [seg, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp,
+                                                       vp, i64, i64, vp, i64, i64, vp]
+    lib.ultra_first_layer_epilogue_backward_workspace.restype = sz
+    lib.ultra_first_layer_epilogue_backward_workspace.argtypes = [i32, i64]
+    lib.ultra_first_layer_epilogue_backward_f32.restype = i32
+    lib.ultra_first_layer_epilogue_backward_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp,
+                                                            vp, vp, vp, vp, sz, i64, vp]
+    lib.ultra_column_sum_blocks.restype = i32
+    lib.ultra_column_sum_blocks.argtypes = []
+    lib.ultra_column_sum_f32.restype = i32
+    lib.ultra_column_sum_f32.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.ultra_dense_layer_supported.restype = i32
     lib.ultra_dense_layer_supported.argtypes = [seg, i64]
     lib.ultra_dense_layer_forward_f32.restype = i32

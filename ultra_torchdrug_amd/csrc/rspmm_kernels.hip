@@ -1738,12 +1738,15 @@ int ultra_first_layer_sparse_supported(int64_t n_dst, int64_t n_rel, int64_t n_q
            n_dst * n_query * 256 < (1LL << 32) - 65536 && n_dst * n_query < 0x7fffffffLL && !g_force_general;
 }
 
-int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *src_ptr, const int32_t *fwd_rank,
-                                 const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
-                                 const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
-                                 const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
-                                 float *out, int32_t *row_list, int64_t row_list_len, int64_t max_runs, int32_t *list_offset,
-                                 int64_t n_dst, int64_t n_rel, void *stream) {
+// `update` == `out`: inference (the epilogue runs in place on the listed rows).  Training passes its own `update` buffer: it
+// receives the frontier's raw rows at the LISTED rows (what the epilogue's backward recomputes from; every other row stays
+// unwritten and is never read) and the epilogue writes `out`.
+static int first_layer_sparse_impl(const ultra_segments *by_src, const int32_t *src_ptr, const int32_t *fwd_rank,
+                                   const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
+                                   const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                                   const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                                   float *update, float *out, int32_t *row_list, int64_t row_list_len, int64_t max_runs,
+                                   int32_t *list_offset, int64_t n_dst, int64_t n_rel, void *stream) {
     int rc = check_segments(by_src);
     if (rc) return rc;
     // a list that cannot hold every query's slots (one per (source, destination) run of its boundary node + its own row) would
@@ -1752,12 +1755,13 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
         max_runs > n_dst || row_list_len < n_query * (max_runs + 1) || row_list_len > 0x7fffffffLL)
         return ULTRA_ERR_BAD_SHAPE;
     if (src_ptr == nullptr || fwd_rank == nullptr || run_prefix == nullptr || relation == nullptr || boundary_node == nullptr ||
-        boundary_value == nullptr || weight == nullptr || bias == nullptr || out == nullptr || row_list == nullptr ||
-        list_offset == nullptr)
+        boundary_value == nullptr || weight == nullptr || bias == nullptr || out == nullptr || update == nullptr ||
+        row_list == nullptr || list_offset == nullptr)
         return ULTRA_ERR_NULL_POINTER;
     if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
     const long long F = n_query * 64;
-    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(relation) | reinterpret_cast<uintptr_t>(boundary_value)) & 15u)
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(update) | reinterpret_cast<uintptr_t>(relation) |
+         reinterpret_cast<uintptr_t>(boundary_value)) & 15u)
         return ULTRA_ERR_BAD_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int dev = 0;
@@ -1786,7 +1790,7 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
     // (2) the frontier's rows over it, listed
     FrontierParams p{};
     p.src_ptr = src_ptr; p.dst = by_src->node_a; p.rel = by_src->rel; p.weight = by_src->weight; p.fwd_rank = fwd_rank;
-    p.relation = relation; p.bnode = boundary_node; p.bvec = boundary_value; p.out = out; p.F = F;
+    p.relation = relation; p.bnode = boundary_node; p.bvec = boundary_value; p.out = update; p.F = F;
     p.piece_len = (int)by_src->piece_len; p.n_rel = (int)n_rel; p.piece_shift = -1;
     for (int sh = 0; sh < 31; ++sh)
         if ((1LL << sh) == by_src->piece_len) p.piece_shift = sh;
@@ -1797,12 +1801,36 @@ int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *sr
     rc = by_src->weight == nullptr ? launch_with_lds(frontier_lds_kernel<true>, p, fgrid, msg_bytes, s, kFrontierLdsThreads)
                                    : launch_with_lds(frontier_lds_kernel<false>, p, fgrid, msg_bytes, s, kFrontierLdsThreads);
     if (rc) return rc;
-    // (3) the epilogue on the listed rows, in place
-    cp.update = out; cp.out = out; cp.rows = n_dst * n_query; cp.row_list = row_list; cp.list_count = list_offset + n_query;
+    // (3) the epilogue on the listed rows (in place in inference)
+    cp.update = update; cp.out = out; cp.rows = n_dst * n_query; cp.row_list = row_list; cp.list_count = list_offset + n_query;
     cp.list_len = (int)row_list_len;
     hipLaunchKernelGGL((combine_kernel<false, 3>), dim3((unsigned)(2 * di->n_cu)), dim3(kCbWaves * 64), lds_cb, s, cp);
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
+}
+
+int ultra_first_layer_sparse_f32(const ultra_segments *by_src, const int32_t *src_ptr, const int32_t *fwd_rank,
+                                 const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
+                                 const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                                 const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                                 float *out, int32_t *row_list, int64_t row_list_len, int64_t max_runs, int32_t *list_offset,
+                                 int64_t n_dst, int64_t n_rel, void *stream) {
+    return first_layer_sparse_impl(by_src, src_ptr, fwd_rank, run_prefix, relation, boundary_node, boundary_value, n_query, weight,
+                                   bias, ln_weight, ln_bias, ln_eps, relu, shortcut, out, out, row_list, row_list_len, max_runs,
+                                   list_offset, n_dst, n_rel, stream);
+}
+
+int ultra_first_layer_sparse_train_f32(const ultra_segments *by_src, const int32_t *src_ptr, const int32_t *fwd_rank,
+                                       const int32_t *run_prefix, const float *relation, const int32_t *boundary_node,
+                                       const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                                       const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                                       float *update, float *out, int32_t *row_list, int64_t row_list_len, int64_t max_runs,
+                                       int32_t *list_offset, int64_t n_dst, int64_t n_rel, void *stream) {
+    if (update == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (update == out) return ULTRA_ERR_BAD_SHAPE;
+    return first_layer_sparse_impl(by_src, src_ptr, fwd_rank, run_prefix, relation, boundary_node, boundary_value, n_query, weight,
+                                   bias, ln_weight, ln_bias, ln_eps, relu, shortcut, update, out, row_list, row_list_len, max_runs,
+                                   list_offset, n_dst, n_rel, stream);
 }
 
 size_t ultra_rspmm_backward_boundary_rows_workspace(int64_t n_query) {
@@ -2045,6 +2073,7 @@ int ultra_combine_forward_boundary_f32(const int32_t *boundary_node, const float
 
 #include "combine_train.inc"
 #include "combine_fused_bwd.inc"
+#include "first_layer_train.inc"
 #include "dense.inc"
 #include "project_bwd.inc"
 #include "sampler.inc"

@@ -261,6 +261,56 @@ def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, l
     return out
 
 
+# First layer in TRAINING sparse end to end (csrc/first_layer_train.inc).  ULTRA_SPARSE_FIRST_LAYER_TRAIN=0: the dense epilogue forward
+# and backward over all N x B rows (same gradients up to the association of three 64-float sums).
+SPARSE_FIRST_LAYER_TRAIN = __import__("os").environ.get("ULTRA_SPARSE_FIRST_LAYER_TRAIN", "1") != "0"
+# ... on graphs where a training batch's boundary nodes (heads of sampled edges: hubs are likely) reach at most this fraction of the
+# nodes each (RelCSR.frontier_fraction): the sparse form's cost grows with the listed rows, the dense form's does not.
+SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION = float(__import__("os").environ.get("ULTRA_SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION", "0.2"))
+
+
+def first_layer_train_forward(csr, relation, boundary, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True,
+                              shortcut=False):
+    """The first layer of an entity Bellman-Ford in training: ``(update, out, row_list, list_count)`` -- ``update`` ``(N, Q, 64)`` holds
+    the frontier's raw sums + boundary at the LISTED rows (every other row is unwritten and never read), ``out`` = the layer's output
+    (the epilogue on the listed rows, one constant row elsewhere; the bits of ``rspmm_frontier`` + ``combine_forward(input_boundary=
+    ...)``), ``row_list`` int32 the listed rows (``node * Q + q``, -1 = empty slot) and ``list_count`` a one-element device tensor with
+    the number of slots in use -- what the epilogue's backward (``ultra_first_layer_epilogue_backward_f32``) works from.  ``None``
+    where the entry does not apply."""
+    if not SPARSE_FIRST_LAYER_TRAIN:
+        return None
+    b_node, b_value = boundary
+    n_dst, n_src, n_rel = csr.shape
+    n_query = b_node.shape[0]
+    lib = _lib.load()
+    if (n_dst != n_src or n_dst * n_query < SPARSE_FIRST_LAYER_MIN_ROWS or n_dst * n_query > (1 << 24) - 64
+            or not lib.ultra_first_layer_sparse_supported(n_dst, n_rel, n_query)
+            or csr.frontier_fraction > SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION):
+        return None
+    F = n_query * 64
+    b_value = b_value.contiguous()
+    if (tuple(relation.shape) != (n_rel, F) or tuple(b_value.shape) != (n_query, 64) or b_node.dtype != torch.int32
+            or not b_node.is_contiguous() or tuple(weight.shape) != (64, 128)):
+        return None
+    relation = relation.contiguous()
+    dev = relation.device
+    src_ptr, fwd_rank = csr.frontier_index
+    run_prefix, max_runs = csr.frontier_runs
+    update = torch.empty(n_dst, n_query, 64, dtype=torch.float32, device=dev)
+    out = torch.empty(n_dst, n_query, 64, dtype=torch.float32, device=dev)
+    row_list = torch.empty(n_query * (max_runs + 1), dtype=torch.int32, device=dev)
+    list_offset = torch.empty(n_query + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.ultra_first_layer_sparse_train_f32(
+            csr.by_src.pointer, src_ptr.data_ptr(), fwd_rank.data_ptr(), run_prefix.data_ptr(), relation.data_ptr(),
+            b_node.data_ptr(), b_value.data_ptr(), n_query, weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+            ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
+            ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
+            update.data_ptr(), out.data_ptr(), row_list.data_ptr(), row_list.numel(), int(max_runs), list_offset.data_ptr(),
+            n_dst, n_rel, _stream()))
+    return update, out, row_list, list_offset[n_query:]
+
+
 # Relation-graph layers in inference as ONE launch where the plan carries its dense form (ultra_dense_layer_forward_f32).
 # ULTRA_DENSE_LAYER=0: the dense rspmm and the epilogue as two launches (same bits).
 DENSE_LAYER = __import__("os").environ.get("ULTRA_DENSE_LAYER", "1") != "0"
@@ -1107,16 +1157,24 @@ class _SumLayerFunction(torch.autograd.Function):
         first_layer = bool(input_is_boundary and boundary is not None and BOUNDARY_ROWS_BACKWARD
                            and frontier_supported("add", mul, flat.shape[1]) and csr.shape[0] == csr.shape[1]
                            and flat.shape[1] == 64 * b_node.shape[0] and b_node.shape[0] <= 65535)
+        sparse = None
         if first_layer and (torch.cuda.is_current_stream_capturing() or bool(torch.isfinite(relation).all())):
             # first layer: only the boundary nodes' out-edges carry a message (same bits as the full kernel, finite tables:
-            # see rspmm_frontier) -- as in inference
-            update = rspmm_frontier(csr, relation.detach(), boundary)
+            # see rspmm_frontier) -- as in inference; and the epilogue runs on the rows they reach only (first_layer_train_forward)
+            if mul == "mul" and grad_tiles is None and not KEEP_PRE_NORM:
+                sparse = first_layer_train_forward(csr, relation.detach(), boundary, weight, bias, ln_weight, ln_bias, ln_eps, relu,
+                                                   shortcut)
+            update = rspmm_frontier(csr, relation.detach(), boundary) if sparse is None else sparse[0].flatten(1)
         else:
             update = rspmm_forward(csr, relation, flat, "add", mul, add_rows=None if add_rows is None else add_rows.flatten(1),
                                    boundary=boundary)
         update = update.view(shape)
         z = torch.empty_like(update) if KEEP_PRE_NORM else None
-        out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut, z_out=z)
+        if sparse is None:
+            out = combine_forward(input, update, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut, z_out=z)
+        else:
+            out = sparse[1].view(shape)
+        ctx.first_rows = None if sparse is None else (sparse[2], sparse[3])
         ctx.csr, ctx.mul, ctx.b_node, ctx.has_add = csr, mul, b_node, add_rows is not None
         # first layer: `input` is the boundary, whose gradient is consumed at row (b_node[q], q) only
         ctx.boundary_rows_only = first_layer
@@ -1150,8 +1208,24 @@ class _SumLayerFunction(torch.autograd.Function):
         d_bias = torch.empty(64, dtype=torch.float32, device=dev)
         d_g = torch.empty(64, dtype=torch.float32, device=dev) if has_ln else None
         d_b = torch.empty(64, dtype=torch.float32, device=dev) if has_ln else None
+        first_rows = getattr(ctx, "first_rows", None)
+        if first_rows is not None:
+            # sparse first layer (csrc/first_layer_train.inc): the listed rows compacted and run through the one-pass backward, every
+            # other row's share of d_bias / d_gamma / d_beta from the column sums of grad_out; d_update is written (and later read) at
+            # the listed rows only, d_input -- which leaves this node -- is zero elsewhere
+            row_list, list_count = first_rows
+            ws1 = torch.empty(int(lib.ultra_first_layer_epilogue_backward_workspace(dev.index or 0, row_list.numel())) // 4,
+                              dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.ultra_first_layer_epilogue_backward_f32(
+                    input_c.data_ptr(), update_c.data_ptr(), grad_out.data_ptr(), row_list.data_ptr(), list_count.data_ptr(),
+                    row_list.numel(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                    ln_weight.contiguous().data_ptr() if has_ln else None, ln_bias.contiguous().data_ptr() if has_ln else None,
+                    ln_eps, int(relu), int(shortcut), d_input.data_ptr(), d_update.data_ptr(), d_weight.data_ptr(), d_bias.data_ptr(),
+                    d_g.data_ptr() if has_ln else None, d_b.data_ptr() if has_ln else None, ws1.data_ptr(), ws1.numel() * 4, rows,
+                    _stream()))
         with torch.cuda.device(dev):
-            _lib.check(lib.ultra_combine_backward_fused_f32(
+            _lib.check(0 if first_rows is not None else lib.ultra_combine_backward_fused_f32(
                 input_c.data_ptr(), update_c.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
                 ln_weight.contiguous().data_ptr() if has_ln else None, ln_bias.contiguous().data_ptr() if has_ln else None,
                 ln_eps, int(relu), int(shortcut), grad_out.data_ptr(), z.data_ptr() if z is not None else None,

@@ -583,6 +583,25 @@ class RelCSR:
             self._frontier_runs = (prefix.contiguous(), int(runs.max()) if runs.numel() else 0)
         return self._frontier_runs
 
+    @property
+    def frontier_fraction(self):
+        """Expected fraction of the nodes that the out-edges of ONE boundary node reach, for boundary nodes drawn like the heads of
+        a training batch -- an edge picked at random, i.e. weighted by out-degree: ``sum_u runs(u) * deg(u) / (E * N)`` with
+        ``runs(u)`` the distinct destinations of ``u``.  A property of the graph (cached; one host read), used to decide statically
+        -- capturable -- whether the first layer of a training step runs sparse (``functional.first_layer_train_forward``)."""
+        base = getattr(self, "_base", None)
+        if base is not None:
+            return base.frontier_fraction
+        if getattr(self, "_frontier_fraction", None) is None:
+            n_dst, n_src, _ = self.shape
+            if not self.n_edges or not n_dst:
+                self._frontier_fraction = 0.0
+            else:
+                runs = torch.bincount(torch.unique(self.src * n_dst + self.dst) // n_dst, minlength=n_src).double()
+                deg = torch.bincount(self.src, minlength=n_src).double()
+                self._frontier_fraction = float((runs * deg).sum() / (deg.sum() * n_dst))
+        return self._frontier_fraction
+
     def with_edge_weights(self, edge_weight):
         """RelCSR over the same edge set with other weights, given per ORIGINAL (un-coalesced) edge; duplicates of
         one triple add up, as ``coalesce()`` would.  Shares the sorted index arrays and chunk schedules."""
