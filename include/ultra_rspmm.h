@@ -304,6 +304,23 @@ int ultra_rspmm_backward_active_f32(const ultra_segments *by_src, const ultra_se
                                     const int32_t *src_active_node, void *stream);
 int ultra_node_bitmap(const int64_t *t_index, int64_t n_batch, int64_t per_row, int64_t n_node, uint32_t *bits, void *stream);
 
+/* d_relation of the FIRST layer (sum aggregation, mul = mul) from the boundary nodes' out-edges alone: the layer's input is zero outside
+ * row src_node[b] of 64-column block b (/root/reference/ultra/model.py:106-107,116-120), so only that node's out-edges contribute to
+ * block b -- a few thousand of the E edges the d_relation plan holds; ultra_rspmm_backward_active_f32(src_active_node) skips their
+ * gathers but still walks all E edge words.  Same bits as that entry (the plan's order: within a relation row by (dst, src), split
+ * rows in pieces of piece_len summed from 0 and added in piece order; a skipped edge would have added +0).
+ *   items      : int32 [n_items][3] {begin, end, target}, one per piece of a split row (target = -(piece_slot + 1)) and one per
+ *                unsplit row (target = the row), [begin, end) in the plan's edge order; n_items = n_pieces + n_rel - n_long_rows
+ *   src_ptr    : int32 [n_src + 1] first out-edge of every source node; src_relpos: int32 [E], for each source node the positions
+ *                of its out-edges in the plan's edge order, ascending
+ *   input      : the layer's input [n_src, F] (row src_node[b] is read at block b); output_grad [n_dst, F]; d_relation [n_rel, F]
+ *   workspace  : n_pieces * F floats
+ * Built once per graph by the host side (relcsr.RelCSR.boundary_relation_index); per-step edge weights come from by_rel->weight. */
+int ultra_rspmm_drelation_boundary_f32(const ultra_segments *by_rel, const int32_t *items, int64_t n_items, const int32_t *src_ptr,
+                                       const int32_t *src_relpos, const int32_t *src_node, const float *input,
+                                       const float *output_grad, float *d_relation, void *workspace, size_t workspace_bytes,
+                                       int64_t n_src, int64_t n_rel, int64_t F, void *stream);
+
 /*
  * d_weight[e] = sum_f output_grad[dst_e, f] * [out == y] * (relation[r_e, f] MUL input[src_e, f])
  * (the value gradient torchdrug returns when sparse.requires_grad), edges in forward-plan order.

@@ -201,6 +201,24 @@ def test_relcsr_matches_oracle_coalesce_and_covers_everything(oracle, kw):
             for a, b, r0, r1 in ch:
                 begin[a:b] = r0
             assert np.array_equal(w & 0xFF, rows - begin)
+    # the first layer's d_relation index: its items are the by_rel plan's pieces and unsplit rows -- the same ranges, the same slots
+    items, src_ptr, src_relpos = csr.boundary_relation_index
+    plan = csr.by_rel
+    it = items.numpy().astype(np.int64)
+    assert it.shape == (plan.n_pieces + r - plan.long_rows.shape[0], 3)
+    pieces = {(a, b, r1) for a, b, _r0, r1 in plan.chunks.numpy().astype(np.int64) if r1 < 0}
+    assert {tuple(x) for x in it if x[2] < 0} == pieces
+    rel_rows = plan.row.numpy()
+    split = set(plan.long_rows.numpy()[:, 0])
+    for a, b, t in it[it[:, 2] >= 0]:
+        assert t not in split and (rel_rows[a:b] == t).all() and b - a == (rel_rows == t).sum()
+    if csr.n_edges:
+        pos, ptr = src_relpos.numpy(), src_ptr.numpy()
+        assert sorted(pos) == list(range(csr.n_edges))
+        src_of = plan.node_a.numpy()
+        for u in range(n):
+            mine = pos[ptr[u]:ptr[u + 1]]
+            assert (np.diff(mine) > 0).all() and (src_of[mine] == u).all()
 
 
 def test_schedule_emulation_reproduces_the_oracle_in_kernel_order(oracle):

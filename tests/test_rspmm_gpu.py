@@ -637,3 +637,18 @@ def test_backward_with_activity_masks_equals_the_full_backward(case, mul):
         _, want = UF.rspmm_backward(csr, relation, boundary, None, dense_grad, "add", "mul", need_input=False)
         _, got = UF.rspmm_backward(csr, relation, boundary, None, dense_grad, "add", "mul", need_input=False, active_src=node)
         assert torch.equal(got, want)
+        # ... and from those nodes' out-edges alone (ultra_rspmm_drelation_boundary_f32): no walk over the other edges at all
+        items, src_ptr, src_relpos = csr.boundary_relation_index
+        assert items.shape[0] == csr.by_rel.n_pieces + r - csr.by_rel.long_rows.shape[0]
+        assert torch.equal(torch.sort(src_relpos.long()).values, torch.arange(csr.n_edges, device=dev))
+        got = UF.rspmm_drelation_boundary(csr, boundary, dense_grad, node)
+        assert torch.equal(got, want)
+        same = node.clone()
+        same[:] = node[0]                                                              # every query at the hub
+        boundary = torch.zeros(n, B, 64, device=dev)
+        boundary[same.long(), torch.arange(B, device=dev)] = torch.randn(B, 64, device=dev, generator=gen)
+        boundary = boundary.flatten(1).contiguous()
+        _, want = UF.rspmm_backward(csr, relation, boundary, None, dense_grad, "add", "mul", need_input=False)
+        assert torch.equal(UF.rspmm_drelation_boundary(csr, boundary, dense_grad, same), want)
+        with pytest.raises(RuntimeError):
+            UF.rspmm_drelation_boundary(csr, boundary, dense_grad, same[:-1].contiguous())

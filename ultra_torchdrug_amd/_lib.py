@@ -67,6 +67,7 @@ EXPORTS = (
     "ultra_rspmm_backward_weight_f32",
     "ultra_rspmm_backward_active_f32",
     "ultra_node_bitmap",
+    "ultra_rspmm_drelation_boundary_f32",
     "ultra_combine_forward_f32",
     "ultra_combine_forward_boundary_f32",
     "ultra_combine_backward_waves",
@@ -182,6 +183,8 @@ def load():
     lib.ultra_rspmm_backward_active_f32.argtypes = [seg, seg, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, i64, i32, vp, i64, vp, vp]
     lib.ultra_node_bitmap.restype = i32
     lib.ultra_node_bitmap.argtypes = [vp, i64, i64, i64, vp, vp]
+    lib.ultra_rspmm_drelation_boundary_f32.restype = i32
+    lib.ultra_rspmm_drelation_boundary_f32.argtypes = [seg, vp, i64, vp, vp, vp, vp, vp, vp, vp, sz, i64, i64, i64, vp]
     lib.ultra_rspmm_backward_weight_f32.restype = i32
     lib.ultra_rspmm_backward_weight_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
     lib.ultra_combine_forward_f32.restype = i32

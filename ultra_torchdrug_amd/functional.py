@@ -357,6 +357,38 @@ def dense_layer_forward(csr, relation, input, boundary, weight, bias, ln_weight=
 ACTIVE_ROW_BACKWARD = __import__("os").environ.get("ULTRA_ACTIVE_ROW_BACKWARD", "1") != "0"
 
 
+# d_relation of the first layer from the boundary nodes' out-edges alone (ultra_rspmm_drelation_boundary_f32) instead of the masked
+# walk over every edge of the graph; ULTRA_BOUNDARY_DRELATION=0: the masked walk.
+BOUNDARY_DRELATION = __import__("os").environ.get("ULTRA_BOUNDARY_DRELATION", "1") != "0"
+
+
+def rspmm_drelation_boundary(csr, input, output_grad, b_node):
+    """``d_relation`` of ``rspmm(sum="add", mul="mul")`` for an ``input`` that is zero outside row ``b_node[q]`` of 64-column block
+    ``q`` (the first Bellman-Ford layer: ``ultra/model.py:106-107,116-120``): only those nodes' out-edges are visited.  Same bits as
+    ``rspmm_backward(..., active_src=b_node)[1]``.  ``input`` ``(N_src, F)``, ``output_grad`` ``(N_dst, F)``, ``b_node`` int32
+    ``(F / 64,)``; returns ``(R, F)``."""
+    input, output_grad = input.contiguous(), output_grad.contiguous()
+    dev, F = input.device, input.shape[1]
+    n_dst, n_src, n_rel = csr.shape
+    if (input.dtype != torch.float32 or output_grad.dtype != torch.float32 or not input.is_cuda or output_grad.device != dev
+            or tuple(input.shape) != (n_src, F) or tuple(output_grad.shape) != (n_dst, F) or F % 64 != 0 or F == 0):
+        raise RuntimeError("rspmm_drelation_boundary: fp32 device tensors (N_src, F) and (N_dst, F) with F a multiple of 64")
+    if b_node.dtype != torch.int32 or not b_node.is_contiguous() or b_node.device != dev or tuple(b_node.shape) != (F // 64,):
+        raise RuntimeError("rspmm_drelation_boundary: b_node must be contiguous int32 (%d,) on %s" % (F // 64, dev))
+    items, src_ptr, src_relpos = csr.boundary_relation_index
+    plan = csr.by_rel
+    d_relation = torch.empty(n_rel, F, dtype=torch.float32, device=dev)
+    n_ws = int(plan.n_pieces) * F
+    ws = torch.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.ultra_rspmm_drelation_boundary_f32(
+            plan.pointer, items.data_ptr(), items.shape[0], src_ptr.data_ptr(), src_relpos.data_ptr(), b_node.data_ptr(),
+            input.data_ptr(), output_grad.data_ptr(), d_relation.data_ptr(), ws.data_ptr() if ws is not None else None, n_ws * 4,
+            n_src, n_rel, F, _stream()))
+    return d_relation
+
+
 def candidate_rows(t_index, n_node):
     """Per query ``b`` the set ``{t_index[b, j]}`` as a bitmap over the nodes, int32 ``(B, ceil(N / 32))`` -- the rows of the LAST
     layer's output the score head reads (``ultra/model.py:177-183``), i.e. the only rows where that output's gradient is
@@ -1237,9 +1269,12 @@ class _SumLayerFunction(torch.autograd.Function):
         flat_du = d_update.flatten(1)
         if ctx.boundary_rows_only and needs[2]:
             # first layer: the input is zero outside row b_node[q] of block q -- d_relation needs that node's out-edges only
-            _, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,
-                                           need_input=False, need_relation=needs[1], active_dst=ctx.grad_rows,
-                                           active_src=ctx.b_node)
+            if needs[1] and BOUNDARY_DRELATION and ctx.mul == "mul" and not ctx.csr.kernel_order("add", "mul", flat_du.shape[1])[1]:
+                d_relation = rspmm_drelation_boundary(ctx.csr, input_c.flatten(1), flat_du, ctx.b_node)
+            else:
+                _, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,
+                                               need_input=False, need_relation=needs[1], active_dst=ctx.grad_rows,
+                                               active_src=ctx.b_node)
             d_in = rspmm_backward_boundary_rows(ctx.csr, relation.contiguous(), flat_du, ctx.b_node, d_input.flatten(1), ctx.mul)
         else:
             d_in, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,

@@ -563,6 +563,46 @@ class RelCSR:
         return self._frontier_index_dense
 
     @property
+    def boundary_relation_index(self):
+        """``(items, src_ptr, src_relpos)`` for :func:`functional.rspmm_drelation_boundary` (``d_relation`` of the first
+        Bellman-Ford layer from the boundary nodes' out-edges): ``items`` int32 ``(n_pieces + n_unsplit_rows, 3)`` -- one
+        ``{begin, end, target}`` per piece of a split row of the ``by_rel`` plan (``target = -(slot + 1)``) and per unsplit row
+        (``target`` = the relation) --, the first out-edge of every source node, and per source node the ``by_rel`` positions of
+        its out-edges, ascending.  Built once per graph (a reweighted RelCSR shares its base's: same plan, other weights)."""
+        base = getattr(self, "_base", None)
+        if base is not None:
+            return base.boundary_relation_index
+        if getattr(self, "_boundary_relation_index", None) is None:
+            plan = self.by_rel
+            n_dst, n_src, n_rel = self.shape
+            dev, E = self.device, self.n_edges
+            rel_ptr = torch.searchsorted(plan.row.long(), torch.arange(n_rel + 1, device=dev)) if E else \
+                torch.zeros(n_rel + 1, dtype=torch.long, device=dev)
+            long_rows = plan.long_rows.long()
+            split = torch.zeros(n_rel, dtype=torch.bool, device=dev)
+            if long_rows.shape[0]:
+                lrow, first_slot, n_p = long_rows[:, 0], long_rows[:, 1], long_rows[:, 2]
+                split[lrow] = True
+                owner = torch.repeat_interleave(torch.arange(lrow.numel(), device=dev), n_p)
+                k = torch.arange(int(n_p.sum()), device=dev) - (torch.cumsum(n_p, 0) - n_p)[owner]
+                begin = rel_ptr[lrow[owner]] + k * plan.piece_len
+                end = torch.minimum(begin + plan.piece_len, rel_ptr[lrow[owner] + 1])
+                pieces = torch.stack([begin, end, -(first_slot[owner] + k + 1)], dim=1)
+            else:
+                pieces = torch.zeros(0, 3, dtype=torch.long, device=dev)
+            rows = torch.nonzero(~split).flatten()
+            whole = torch.stack([rel_ptr[rows], rel_ptr[rows + 1], rows], dim=1)
+            items = torch.cat([pieces, whole], dim=0).to(torch.int32).contiguous()
+            src_ptr = self.frontier_index[0]
+            if E:
+                key = plan.node_a.long() * E + torch.arange(E, device=dev)       # (source, plan position), positions distinct
+                src_relpos = (torch.sort(key).values % E).to(torch.int32).contiguous()
+            else:
+                src_relpos = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._boundary_relation_index = (items, src_ptr, src_relpos)
+        return self._boundary_relation_index
+
+    @property
     def frontier_runs(self):
         """``(run_prefix, max_runs)`` for :func:`functional.first_layer_forward`: for every edge of the ``by_src`` order
         (sorted by (src, dst, rel)) the number of (source, destination) runs that start at or before it -- int32 ``(E,)`` -- and
