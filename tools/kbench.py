@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--relgraph", action="store_true", help="the workload's RELATION graph (2R nodes, 4 edge types) instead of the entity graph")
     ap.add_argument("--weights", action="store_true", help="per-edge weights (0 for 1 %% of the edges, 1 elsewhere): the training step's edge removal")
     ap.add_argument("--hot", action="store_true", help="plans with the LDS hot-row cache (kernel VAR 4)")
+    ap.add_argument("--reserve", type=int, default=0, help="ultra_rspmm_reserve_cus: size the persistent grids for this many compute units fewer")
     ap.add_argument("--combine", action="store_true", help="time the fused layer epilogue (forward, or fwd+bwd with --backward)")
     args = ap.parse_args()
     import ultra_torchdrug_amd as U
@@ -34,6 +35,8 @@ def main():
     from ultra_torchdrug_amd.data import synthetic_kg
     lib = U.require_library()
     lib.ultra_rspmm_force_general_path((1 if args.general else 0) | args.knob)
+    if args.reserve:
+        lib.ultra_rspmm_reserve_cus(args.reserve)
     dev = torch.device("cuda:0")
     g = synthetic_kg(args.workload, device=dev)
     if args.relgraph:
