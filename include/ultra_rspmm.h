@@ -93,6 +93,12 @@ typedef struct ultra_segments {
     const uint32_t *dense;
     int64_t dense_rows;        /* nodes along the matrix's 16-row tiles (forward: n_dst, d_input: n_src, d_relation: n_dst) */
     int64_t dense_cols;        /* gathered nodes (forward: n_src, d_input: n_dst, d_relation: n_src)                        */
+    /* optional (ABI 7; ultra_edge_removal_marks): a copy of `packed` in which bit 31 is set for every edge whose weight is     */
+    /* exactly 0, for plans whose other weights are all exactly 1 (the training step's edge removal on a unit-weight graph,    */
+    /* /root/reference/ultra/model.py:57-74): the sum / mul kernels then run their unit-weight form on these words -- a marked   */
+    /* edge issues its gathers past the buffer descriptors and contributes the (+-0) a zero weight contributes -- and never      */
+    /* read `weight`; kernels without that form use `packed` + `weight` as before.  NULL = none.                              */
+    const uint32_t *packed_dead;
 } ultra_segments;
 
 int ultra_rspmm_abi_version(void);
@@ -120,7 +126,7 @@ int ultra_rspmm_event_elapsed_ms(void *start_event, void *stop_event, float *ms_
  * chunks per wave (quad_kernel) would run, bit 3 the chunked kernels where one row per 16-lane group (rowgroup_kernel)
  * would run, bit 4 the wide-group forms of that kernel (32 / 64 lanes per row, column tiles of 128 / 256) on inputs small
  * enough to be cache-resident, bit 5 makes quad_kernel walk a label's column tiles one after the other where it would
- * work on several at once (small graphs), bit 6 walks the edge list of a plan that carries a dense form.  Bit 0 also selects the L2-row form of the first-layer frontier kernel where the
+ * work on several at once (small graphs), bit 6 walks the edge list of a plan that carries a dense form, bit 7 runs the weighted kernels where a plan carries marked words (packed_dead).  Bit 0 also selects the L2-row form of the first-layer frontier kernel where the
  * LDS-message form would run.  All paths return identical bits. */
 int ultra_rspmm_force_general_path(int on);
 
@@ -578,6 +584,14 @@ int ultra_strict_negative(const int64_t *keys, int64_t n_keys, const int64_t *an
 int ultra_edge_removal_weights(const ultra_segments *fwd, const ultra_segments *by_src, const ultra_segments *by_rel,
                                const int64_t *h, const int64_t *t, const int64_t *r, int64_t n_pattern,
                                int64_t n_base_rel, float *w_fwd, float *w_src, float *w_rel, int64_t slack, void *stream);
+/* As ultra_edge_removal_weights, and ALSO the marked word copies that ultra_segments.packed_dead takes (any of them NULL: that plan
+ * gets none): words_x = the plan's packed words (n_edges + slack of them) with bit 31 set where w_x is set to 0.  Only for plans
+ * WITHOUT weights of their own (every weight exactly 1) whose packed words leave bit 31 free (node ids inside the word, id range
+ * below 2^(31 - packed_src_shift)): ULTRA_ERR_BAD_SHAPE otherwise.  One fill launch for all six arrays + the search launch. */
+int ultra_edge_removal_marks(const ultra_segments *fwd, const ultra_segments *by_src, const ultra_segments *by_rel,
+                             const int64_t *h, const int64_t *t, const int64_t *r, int64_t n_pattern, int64_t n_base_rel,
+                             float *w_fwd, float *w_src, float *w_rel, int64_t slack, uint32_t *words_fwd, uint32_t *words_src,
+                             uint32_t *words_rel, int64_t n_node, void *stream);
 
 
 /*

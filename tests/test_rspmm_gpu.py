@@ -652,3 +652,60 @@ def test_backward_with_activity_masks_equals_the_full_backward(case, mul):
         assert torch.equal(UF.rspmm_drelation_boundary(csr, boundary, dense_grad, same), want)
         with pytest.raises(RuntimeError):
             UF.rspmm_drelation_boundary(csr, boundary, dense_grad, same[:-1].contiguous())
+
+
+@pytest.mark.parametrize("mul", ["mul", "add"])
+def test_removed_edges_as_marked_words_equal_zero_weights(mul):
+    """The training step's edge removal on a unit-weight graph (``RelCSR.with_removed_edges``) hands the sum / mul kernels copies of the
+    packed words with bit 31 set at the removed edges (``ultra_edge_removal_marks``, quad.inc DEAD) beside the zero weights: forward,
+    d_input, d_relation -- full and with the last layer's destination masks -- must EQUAL what the weighted kernels give (knob bit 7)
+    and what a plainly reweighted graph gives; the TransE message keeps the weighted kernels."""
+    from ultra_torchdrug_amd import RelCSR, _lib, functional as UF
+    dev = _dev()
+    n, r = 14541, 474
+    g = kg_graph(1024, n, 272115, 237)
+    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), None, n, n, r)
+    gen = torch.Generator(device=dev).manual_seed(11 + (mul == "add"))
+    # triples to remove: 64 real edges (hub rows among them), listed with repeats, + 200 patterns that are no edges
+    deg = torch.bincount(csr.dst, minlength=n)
+    hub_edges = torch.nonzero(csr.dst == int(deg.argmax())).flatten()[:8]
+    pick = torch.cat([torch.randint(0, csr.n_edges, (56,), device=dev, generator=gen), hub_edges])
+    pick = pick[csr.rel_id[pick] < r // 2]                                  # base relations: the call removes the inverse itself
+    h = torch.cat([csr.src[pick], csr.src[pick][:5], torch.randint(0, n, (200,), device=dev, generator=gen)])
+    t = torch.cat([csr.dst[pick], csr.dst[pick][:5], torch.randint(0, n, (200,), device=dev, generator=gen)])
+    rel = torch.cat([csr.rel_id[pick], csr.rel_id[pick][:5], torch.randint(0, r // 2, (200,), device=dev, generator=gen)])
+    cut = csr.with_removed_edges(h, t, rel, r // 2)
+    for plan, base in ((cut.fwd, csr.fwd), (cut.by_src, csr.by_src), (cut.by_rel, csr.by_rel)):
+        assert plan.packed_dead is not None and plan.struct.packed_dead == plan.packed_dead.data_ptr()
+        E = csr.n_edges
+        marked = (plan.packed_dead[:E].long() & 0x80000000) != 0
+        assert torch.equal(marked, plan.weight[:E] == 0) and int(marked.sum()) >= torch.unique(pick).numel()
+        assert torch.equal(plan.packed_dead.long() & 0x7fffffff, base.packed.long() & 0xffffffff)
+        assert torch.equal(plan.packed, base.packed)
+    B = 16
+    F = B * 64
+    relation = torch.randn(r, F, device=dev, generator=gen)
+    x = torch.randn(n, F, device=dev, generator=gen)
+    grad = torch.randn(n, F, device=dev, generator=gen)
+    t_index = torch.randint(0, n, (B, 129), device=dev, generator=gen)
+    bits = UF.candidate_rows(t_index, n)
+    member = torch.zeros(B, n, dtype=torch.bool, device=dev)
+    member[torch.arange(B, device=dev).unsqueeze(-1), t_index] = True
+    sparse_grad = (torch.randn(n, B, 64, device=dev, generator=gen) * member.t().unsqueeze(-1)).flatten(1).contiguous()
+    lib = _lib.load()
+
+    def run():
+        out = UF.rspmm_forward(cut, relation, x, "add", mul)
+        dx, drel = UF.rspmm_backward(cut, relation, x, None, grad, "add", mul)
+        dx2, drel2 = UF.rspmm_backward(cut, relation, x, None, sparse_grad, "add", mul, active_dst=bits)
+        return out, dx, drel, dx2, drel2
+
+    got = run()
+    lib.ultra_rspmm_force_general_path(128)              # bit 7: the weighted kernels
+    try:
+        want = run()
+    finally:
+        lib.ultra_rspmm_force_general_path(0)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not torch.equal(got[0], UF.rspmm_forward(csr, relation, x, "add", mul))       # (the removal does change the result)

@@ -39,6 +39,7 @@ class UltraSegments(ctypes.Structure):
         ("dense", ctypes.c_void_p),
         ("dense_rows", ctypes.c_int64),
         ("dense_cols", ctypes.c_int64),
+        ("packed_dead", ctypes.c_void_p),
     ]
 
 
@@ -84,6 +85,7 @@ EXPORTS = (
     "ultra_filtered_rank_keys",
     "ultra_strict_negative",
     "ultra_edge_removal_weights",
+    "ultra_edge_removal_marks",
     "ultra_prepare_queries",
     "ultra_relation_stack_inputs",
     "ultra_statistics_blocks",
@@ -238,6 +240,8 @@ def load():
     lib.ultra_strict_negative.argtypes = [vp, i64, vp, vp, i64, i64, i64, vp, i64, vp, vp]
     lib.ultra_edge_removal_weights.restype = i32
     lib.ultra_edge_removal_weights.argtypes = [seg, seg, seg, vp, vp, vp, i64, i64, vp, vp, vp, i64, vp]
+    lib.ultra_edge_removal_marks.restype = i32
+    lib.ultra_edge_removal_marks.argtypes = [seg, seg, seg, vp, vp, vp, i64, i64, vp, vp, vp, i64, vp, vp, vp, i64, vp]
     lib.ultra_relcsr_coalesce_temp_bytes.restype = sz
     lib.ultra_relcsr_coalesce_temp_bytes.argtypes = [i64]
     lib.ultra_relcsr_coalesce.restype = i32

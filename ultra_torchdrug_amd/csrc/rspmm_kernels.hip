@@ -950,6 +950,7 @@ bool g_force_general = false;
 bool g_no_x_lds = false;
 bool g_no_quad = false;
 bool g_wide_groups = false;
+bool g_no_dead_words = false;
 #ifndef ULTRA_QUAD_U
 #define ULTRA_QUAD_U 8
 #endif
@@ -1137,7 +1138,17 @@ int launch_packed(const PParams &p, int sum_op, int mul_op, bool unit_w, int var
 }
 
 template <int KIND, int SUM, int MUL>
-int launch_quad_w(const PParams &p, bool unit_w, bool x_lds, int grid, size_t lds, hipStream_t stream) {
+int launch_quad_w(const PParams &p, bool unit_w, bool x_lds, int grid, size_t lds, hipStream_t stream, bool dead = false) {
+    // the plan's marked word copy (quad.inc DEAD): removed edges by bit 31, every other weight 1 -- run_plan decides
+    if constexpr (SUM == ULTRA_SUM_ADD && MUL == ULTRA_MUL_MUL) {
+        if (dead && !x_lds && p.act_node == nullptr) {
+            if constexpr (KIND == KIND_DREL) {
+                if (p.act_bits != nullptr)
+                    return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, false, kQuadU, 2, true>, p, grid, lds, stream);
+            }
+            return launch_with_lds(quad_kernel<KIND, SUM, MUL, true, false, kQuadU, 0, true>, p, grid, lds, stream);
+        }
+    }
     // activity masks (see quad.inc ACT): d_relation only.  The d_input form (ACT = 1) was built and measured: that kernel is
     // bound by its per-row epilogue (read-modify-write of the gradient it accumulates into) and per-edge issue, not by its
     // gathers -- 137 vs 138 us on the FB15k237-shaped graph, 156 vs 148 us on the WN18RR-shaped one with the mask -- so it is
@@ -1164,10 +1175,10 @@ int launch_quad_w(const PParams &p, bool unit_w, bool x_lds, int grid, size_t ld
 
 template <int KIND>
 int launch_quad(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_lds, int grid, size_t lds,
-                hipStream_t stream) {
+                hipStream_t stream, bool dead = false) {
     if constexpr (KIND == KIND_FWD) {
 #define ULTRA_QCASE(S, M) \
-    if (sum_op == S && mul_op == M) return launch_quad_w<KIND_FWD, S, M>(p, unit_w, x_lds, grid, lds, stream);
+    if (sum_op == S && mul_op == M) return launch_quad_w<KIND_FWD, S, M>(p, unit_w, x_lds, grid, lds, stream, dead);
         ULTRA_QCASE(ULTRA_SUM_ADD, ULTRA_MUL_MUL)
         ULTRA_QCASE(ULTRA_SUM_ADD, ULTRA_MUL_ADD)
         ULTRA_QCASE(ULTRA_SUM_MIN, ULTRA_MUL_MUL)
@@ -1176,10 +1187,10 @@ int launch_quad(const PParams &p, int sum_op, int mul_op, bool unit_w, bool x_ld
         ULTRA_QCASE(ULTRA_SUM_MAX, ULTRA_MUL_ADD)
 #undef ULTRA_QCASE
     } else if constexpr (KIND == KIND_DX) {
-        if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream);
+        if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream, dead);
         return launch_quad_w<KIND_DX, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, x_lds, grid, lds, stream);
     } else {
-        if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream);
+        if (mul_op == ULTRA_MUL_MUL) return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_MUL>(p, unit_w, x_lds, grid, lds, stream, dead);
         return launch_quad_w<KIND_DREL, ULTRA_SUM_ADD, ULTRA_MUL_ADD>(p, unit_w, false, grid, p.act_bits != nullptr ? lds : (size_t)kLdsHeader, stream);
     }
     return ULTRA_ERR_BAD_OP;
@@ -1468,7 +1479,12 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
                         q.act_node = p.act_node;      // (mul = add: d_relation does not depend on the input rows)
                     }
                 }
-                rc = launch_quad<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var == 1, grid, kLdsHeader + lds_bytes + act_bytes, stream);
+                // removed edges marked in a copy of the words (ultra_segments.packed_dead): the unit-weight kernel on those words
+                const bool dead = seg->packed_dead != nullptr && !g_no_dead_words && var == 0 && q.act_node == nullptr &&
+                                  sum_op == ULTRA_SUM_ADD && mul_op == ULTRA_MUL_MUL;
+                if (dead) { q.meta = seg->packed_dead; q.weight = nullptr; }
+                rc = launch_quad<KIND>(q, sum_op, mul_op, dead || seg->weight == nullptr, var == 1, grid,
+                                       kLdsHeader + lds_bytes + act_bytes, stream, dead);
             }
             if (!quad) rc = launch_packed<KIND>(q, sum_op, mul_op, seg->weight == nullptr, var, grid, kLdsHeader + lds_bytes, stream);
             if (rc) return rc;
@@ -1556,6 +1572,7 @@ int ultra_rspmm_force_general_path(int on) {
     g_no_rowgroup = (on & 8) != 0;        // bit 3: chunked kernels where one row per group (rowgroup_kernel) would run
     g_wide_groups = (on & 16) != 0;       // bit 4: rowgroup_kernel with 32 / 64 lanes per row even for cache-sized inputs
     g_no_concurrent_tiles = (on & 32) != 0;   // bit 5: quad_kernel walks a label's column tiles one after the other
+    g_no_dead_words = (on & 128) != 0;    // bit 7: the weighted kernels even where a plan carries marked words (packed_dead)
     g_no_dense = (on & 64) != 0;          // bit 6: the edge list of a plan that carries a dense form (relgraph_dense.hip)
     return ULTRA_OK;
 }

@@ -57,6 +57,8 @@ def auto_sizes(n_edges, wide=False, n_rows=None):
 
 CHUNK_EDGES, PIECE_LEN = auto_sizes(0)    # the sizes small graphs get (kept as names for explicit callers / tests)
 PACK_SLACK = 16      # readable words after the last edge of `packed` / `weight` (whole-batch loads)
+# per-step edge removal on unit-weight graphs: marked word copies beside the zero weights (ultra_edge_removal_marks); 0: weights only
+DEAD_EDGE_WORDS = os.environ.get("ULTRA_DEAD_EDGE_WORDS", "1") != "0"
 LDS_TABLE_BYTES = 156 * 1024 - 16    # LDS the kernels give to the relation tile + hot-row cache (csrc: kMaxLdsBytes)
 HOT_MAX = 512        # at most this many cached rows
 HOT_MIN_COVERAGE = 0.2   # build a hot-row cache only if it serves at least this fraction of the gathers
@@ -230,6 +232,8 @@ class Segments:
         s.row_ptr = self.row_ptr.data_ptr() if self.row_ptr is not None else None
         s.dense = self.dense.data_ptr() if self.dense is not None else None
         s.dense_rows, s.dense_cols = self.dense_rows, self.dense_cols
+        dead = getattr(self, "packed_dead", None)
+        s.packed_dead = dead.data_ptr() if dead is not None else None
 
     def attach_dense(self, n_rows, n_cols, kind):
         """Build the plan's 0/1 matrix natively (``ultra_relcsr_dense``) and hang it on the struct.  ``kind`` 0: rows of the
@@ -273,17 +277,20 @@ class Segments:
         (``weight``: fp32 [n_edges] in THIS plan's edge order)."""
         import copy
         other = copy.copy(self)
+        other.packed_dead = None
         other.weight = torch.cat([weight.to(torch.float32),
                                   torch.ones(PACK_SLACK, dtype=torch.float32, device=weight.device)]).contiguous()
         other.struct = _lib.UltraSegments()
         other._refresh_struct()
         return other
 
-    def with_weight_buffer(self, buffer):
-        """As :meth:`reweighted`, for a weight array that already carries its ``PACK_SLACK`` trailing ones."""
+    def with_weight_buffer(self, buffer, packed_dead=None):
+        """As :meth:`reweighted`, for a weight array that already carries its ``PACK_SLACK`` trailing ones.  ``packed_dead``: a copy
+        of ``packed`` with bit 31 set where ``buffer`` is 0, for weights that are otherwise all 1 (``ultra_edge_removal_marks``)."""
         import copy
         other = copy.copy(self)
         other.weight = buffer
+        other.packed_dead = packed_dead
         other.struct = _lib.UltraSegments()
         other._refresh_struct()
         return other
@@ -672,11 +679,25 @@ class RelCSR:
         E = base.n_edges
         plans = (self.fwd, self.by_src, self.by_rel)         # their weights are the starting point
         w = [torch.empty(E + PACK_SLACK, dtype=torch.float32, device=dev) for _ in range(3)]
+        # a graph of unit weights whose packed words leave bit 31 free: the removed edges ALSO as marks in copies of the words, on
+        # which the sum / mul kernels run their unit-weight form (csrc/quad.inc DEAD) instead of loading a weight per edge
+        n_node = max(self.shape[0], self.shape[1])
+        marks = [None, None, None]
+        if (DEAD_EDGE_WORDS and self.unit_weight and self.shape[0] == self.shape[1] and E and
+                all(p.weight is None and p.packed is not None and p.packed_src_shift < 31
+                    and (n_node - 1) >> (31 - p.packed_src_shift) == 0 for p in plans)):
+            marks = [torch.empty(E + PACK_SLACK, dtype=torch.int32, device=dev) for _ in range(3)]
         with torch.cuda.device(dev):
-            _lib.check(lib.ultra_edge_removal_weights(
-                plans[0].pointer, plans[1].pointer, plans[2].pointer, h.data_ptr(), t.data_ptr(), r.data_ptr(),
-                h.numel(), int(n_base_rel), w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(), PACK_SLACK,
-                torch.cuda.current_stream().cuda_stream))
+            if marks[0] is not None:
+                _lib.check(lib.ultra_edge_removal_marks(
+                    plans[0].pointer, plans[1].pointer, plans[2].pointer, h.data_ptr(), t.data_ptr(), r.data_ptr(),
+                    h.numel(), int(n_base_rel), w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(), PACK_SLACK,
+                    marks[0].data_ptr(), marks[1].data_ptr(), marks[2].data_ptr(), n_node, torch.cuda.current_stream().cuda_stream))
+            else:
+                _lib.check(lib.ultra_edge_removal_weights(
+                    plans[0].pointer, plans[1].pointer, plans[2].pointer, h.data_ptr(), t.data_ptr(), r.data_ptr(),
+                    h.numel(), int(n_base_rel), w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(), PACK_SLACK,
+                    torch.cuda.current_stream().cuda_stream))
         other = RelCSR.__new__(RelCSR)
         other.shape, other._opts = self.shape, self._opts
         other.chunk_edges, other.piece_len = self.chunk_edges, self.piece_len
@@ -685,9 +706,9 @@ class RelCSR:
         other.weight, other.unit_weight = w[0][:E], False
         other.dense_form = False
         other._base = base
-        other._fwd = plans[0].with_weight_buffer(w[0])
-        other._by_src = plans[1].with_weight_buffer(w[1])
-        other._by_rel = plans[2].with_weight_buffer(w[2])
+        other._fwd = plans[0].with_weight_buffer(w[0], marks[0])
+        other._by_src = plans[1].with_weight_buffer(w[1], marks[1])
+        other._by_rel = plans[2].with_weight_buffer(w[2], marks[2])
         return other
 
     @property
