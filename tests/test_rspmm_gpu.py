@@ -664,7 +664,9 @@ def test_removed_edges_as_marked_words_equal_zero_weights(mul):
     dev = _dev()
     n, r = 14541, 474
     g = kg_graph(1024, n, 272115, 237)
-    csr = RelCSR(_t(g["dst"]), _t(g["src"]), _t(g["rel"]), None, n, n, r)
+    distinct = np.unique(np.stack([g["dst"], g["src"], g["rel"]]), axis=1)      # a KG lists a triple once: every weight is 1
+    csr = RelCSR(_t(distinct[0]), _t(distinct[1]), _t(distinct[2]), None, n, n, r)
+    assert csr.unit_weight
     gen = torch.Generator(device=dev).manual_seed(11 + (mul == "add"))
     # triples to remove: 64 real edges (hub rows among them), listed with repeats, + 200 patterns that are no edges
     deg = torch.bincount(csr.dst, minlength=n)
