@@ -298,6 +298,11 @@ def test_state_dict_contract():
                      q + "layer_norm.bias": (64,), q + "relation.weight": (4, 64)})
     assert {k: tuple(v.shape) for k, v in sd.items()} == want
     assert sum(v.numel() for v in sd.values()) == 194113
+    # the one number the reference states about the model (/root/reference/README.md:57: "6-layer GNNs per relation and entity
+    # graphs, 64d, 168k total parameters"): the parameters a training step reaches -- everything but the two modules the
+    # reference constructs and never calls (the relation model's mlp, the entity model's dist_embed)
+    unused = ("rel_models.0.model.mlp.", "model.dist_embed.")
+    assert sum(v.numel() for k, v in sd.items() if not k.startswith(unused)) == 168705          # "168k"
     task.load_state_dict({k: torch.zeros(s) for k, s in want.items()}, strict=True)
 
 
