@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--boundary", action="store_true", help="forward with the fused `+ boundary` epilogue (add_rows), as inside a layer")
     ap.add_argument("--relgraph", action="store_true", help="the workload's RELATION graph (2R nodes, 4 edge types) instead of the entity graph")
     ap.add_argument("--weights", action="store_true", help="per-edge weights (0 for 1 %% of the edges, 1 elsewhere): the training step's edge removal")
+    ap.add_argument("--removed", action="store_true", help="64 edges (and their inverses) removed as a training step removes them: zero weights + marked "
+                    "words (RelCSR.with_removed_edges); with --knob 128 the weighted kernels run on the same plans")
     ap.add_argument("--hot", action="store_true", help="plans with the LDS hot-row cache (kernel VAR 4)")
     ap.add_argument("--reserve", type=int, default=0, help="ultra_rspmm_reserve_cus: size the persistent grids for this many compute units fewer")
     ap.add_argument("--combine", action="store_true", help="time the fused layer epilogue (forward, or fwd+bwd with --backward)")
@@ -49,6 +51,10 @@ def main():
     if args.weights:
         wgen = torch.Generator(device="cpu").manual_seed(1)
         csr = csr.with_edge_weights((torch.rand(g.edge_list.shape[0], generator=wgen) > 0.01).float().to(dev))
+    if args.removed:
+        pick = torch.randperm(csr.n_edges, generator=torch.Generator(device="cpu").manual_seed(2))[:256].to(dev)
+        pick = pick[csr.rel_id[pick] < g.num_relation // 2][:64]
+        csr = csr.with_removed_edges(csr.src[pick], csr.dst[pick], csr.rel_id[pick], g.num_relation // 2)
     F = args.batch * 64
     gen = torch.Generator(device="cpu").manual_seed(0)
     relation = torch.randn(g.num_relation, F, generator=gen).to(dev)
