@@ -711,3 +711,54 @@ def test_removed_edges_as_marked_words_equal_zero_weights(mul):
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     assert not torch.equal(got[0], UF.rspmm_forward(csr, relation, x, "add", mul))       # (the removal does change the result)
+
+
+@pytest.mark.parametrize("shape", ["small", "hub_split", "wide_ids", "no_free_bit"])
+def test_removed_edges_on_other_plan_shapes_equal_plain_reweighting(shape):
+    """``with_removed_edges`` against a RelCSR that simply carries the zero weights (no marks: the weighted kernels), on plan shapes the
+    KG-sized test does not reach: a graph of a few chunks, hub rows cut into pieces, node ids outside the packed word and a node range
+    that leaves no free bit (both: no marks, weights only), every edge of one row removed."""
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    dev = _dev()
+    opts = {}
+    if shape == "small":
+        n, r, g = 300, 6, random_graph(seed=3, n_node=300, n_edge=2500, n_rel=6)
+    elif shape == "hub_split":
+        n, r, g = 900, 14, random_graph(seed=8, n_node=900, n_edge=30000, n_rel=14, skew=True, hub_row=5, hub_edges=4000)
+        opts = dict(chunk_edges=16, piece_len=64)
+    elif shape == "wide_ids":
+        n, r, g = 700, 10, random_graph(seed=5, n_node=700, n_edge=9000, n_rel=10)
+        opts = dict(wide_ids=True)
+    else:
+        n, r, g = 20000, 474, random_graph(seed=6, n_node=20000, n_edge=40000, n_rel=474)     # 8 + 9 + 15 bits: the word is full
+    distinct = np.unique(np.stack([g["dst"], g["src"], g["rel"]]), axis=1)
+    keep = distinct[2] < r // 2                                              # base relations; the inverses are added below
+    d, s_, rel_ = distinct[0][keep], distinct[1][keep], distinct[2][keep]
+    dst = np.concatenate([d, s_]); src = np.concatenate([s_, d]); rel = np.concatenate([rel_, rel_ + r // 2])
+    both = np.unique(np.stack([dst, src, rel]), axis=1)
+    csr = RelCSR(_t(both[0]), _t(both[1]), _t(both[2]), None, n, n, r, **opts)
+    assert csr.unit_weight
+    gen = torch.Generator(device=dev).manual_seed(zlib.crc32(shape.encode()) % 1000)
+    row = int(torch.bincount(csr.dst, minlength=n).argmax())
+    whole_row = torch.nonzero((csr.dst == row) & (csr.rel_id < r // 2)).flatten()          # every base edge into the heaviest row
+    pick = torch.cat([whole_row, torch.randint(0, csr.n_edges, (40,), device=dev, generator=gen)])
+    pick = pick[csr.rel_id[pick] < r // 2]
+    h, t, rr = csr.src[pick], csr.dst[pick], csr.rel_id[pick]
+    cut = csr.with_removed_edges(h, t, rr, r // 2)
+    marked = cut.fwd.packed_dead is not None
+    assert marked == (shape in ("small", "hub_split"))
+    # the same zero weights on a RelCSR of its own (plans rebuilt with weights: no marks anywhere)
+    w = cut.weight.clone()
+    ref = RelCSR(csr.dst, csr.src, csr.rel_id, w, n, n, r, **opts)
+    assert ref.fwd.weight is not None and getattr(ref.fwd, "packed_dead", None) is None
+    F = 256
+    relation = torch.randn(r, F, device=dev, generator=gen)
+    x = torch.randn(n, F, device=dev, generator=gen)
+    grad = torch.randn(n, F, device=dev, generator=gen)
+    for mul in ("mul", "add"):
+        out_a = UF.rspmm_forward(cut, relation, x, "add", mul)
+        out_b = UF.rspmm_forward(ref, relation, x, "add", mul)
+        assert torch.equal(out_a, out_b), (shape, mul)
+        da, ra = UF.rspmm_backward(cut, relation, x, None, grad, "add", mul)
+        db, rb = UF.rspmm_backward(ref, relation, x, None, grad, "add", mul)
+        assert torch.equal(da, db) and torch.equal(ra, rb), (shape, mul)
