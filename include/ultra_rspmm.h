@@ -41,7 +41,7 @@ extern "C" {
  * (tests/test_host_logic.py compares `nm -D` of the built library with this header). */
 #pragma GCC visibility push(default)
 
-#define ULTRA_RSPMM_ABI_VERSION 7
+#define ULTRA_RSPMM_ABI_VERSION 8
 
 /* sum= / mul= of generalized_rspmm (layer.py:134-167: sum in {"add","max","min"}, mul in {"mul","add"}) */
 enum ultra_sum_op { ULTRA_SUM_ADD = 0, ULTRA_SUM_MIN = 1, ULTRA_SUM_MAX = 2 };
@@ -54,11 +54,19 @@ enum ultra_status {
     ULTRA_ERR_NULL_POINTER = 3,
     ULTRA_ERR_WORKSPACE = 4,     /* workspace smaller than ultra_rspmm_workspace_bytes() */
     ULTRA_ERR_HIP = 5,           /* a HIP runtime call failed; see ultra_rspmm_last_hip_error() */
-    ULTRA_ERR_NO_DEVICE = 6      /* no gfx950 device visible */
+    ULTRA_ERR_NO_DEVICE = 6,     /* no gfx950 device visible */
+    ULTRA_ERR_ABI = 7            /* an ultra_segments whose struct_bytes / abi_version are not this library's (a binding   */
+                                 /* written against another header): nothing of the struct beyond those two fields is read */
 };
 
 /* One ordered reduction plan over the edge list (all arrays in device memory, built once per graph). */
 typedef struct ultra_segments {
+    /* ABI 8: the fence.  A binding sets struct_bytes = sizeof(ultra_segments) of the header it was written against  */
+    /* (== ultra_segments_bytes() of the library it loads) and abi_version = ULTRA_RSPMM_ABI_VERSION; every entry    */
+    /* point that takes a plan checks both FIRST and returns ULTRA_ERR_ABI otherwise -- a struct declared from an   */
+    /* older header (a field short) is refused instead of being read past its end.                                   */
+    uint32_t struct_bytes;
+    uint32_t abi_version;
     int64_t n_rows;            /* number of target rows of this plan                                   */
     int64_t n_edges;           /* coalesced edge count E                                                */
     const int32_t *row;        /* [E] target row of each edge, non-decreasing                           */
@@ -102,6 +110,8 @@ typedef struct ultra_segments {
 } ultra_segments;
 
 int ultra_rspmm_abi_version(void);
+/* sizeof(ultra_segments) as THIS library was compiled (ABI 8): what a binding's own declaration of the struct must measure. */
+size_t ultra_segments_bytes(void);
 const char *ultra_rspmm_status_string(int status);
 /* hipError_t of the last failing HIP call on this thread (0 if none). */
 int ultra_rspmm_last_hip_error(void);
@@ -565,7 +575,10 @@ int ultra_filtered_rank(const float *pred, int64_t n_query, int64_t n_cand, int6
  * ultra_filtered_rank_keys: get_ranking (ultra/task.py:307-315) with the filter mask of ultra/task.py:65-100 looked up
  *   in `keys`:  rank = 1 + #{c : pos <= pred[c]} - #{c completes (anchor_q, rel_q, ?) : pos <= pred[c]}.
  *   Query q reads pred + q * row_stride (n_cand = n_node scores), target[q * target_stride], anchor / rel
- *   [q * index_stride] and writes rank[q * rank_stride]; keys == NULL: unfiltered ranking.
+ *   [q * index_stride] and writes rank[q * rank_stride]; keys == NULL: unfiltered ranking.  Rows of more than 64 K
+ *   candidates are counted by several workgroups each (ABI 8: one workgroup per query took 32 ms for two rows of 10 M
+ *   candidates): a first launch writes 1 - (filtered count), a second adds the slices' counts with integer atomics -- the
+ *   same int64 whatever the order.
  * ultra_strict_negative: strict negative sampling (ultra/task.py:102-118) without mask.nonzero(): out[q, s] is the
  *   floor(rand[q, s] * n_free_q)-th entity in ascending order that does NOT complete (anchor_q, rel_q, ?) -- the entity
  *   torchdrug's variadic_sample picks for the same uniform numbers.  rand fp32 [n_query, n_sample] in [0, 1).
@@ -661,6 +674,21 @@ int ultra_dense_layer_forward_f32(const ultra_segments *fwd, const float *relati
                                   const int32_t *boundary_node, const float *boundary_value, int64_t n_query, const float *weight,
                                   const float *bias, const float *ln_weight, const float *ln_bias, float ln_eps, int relu,
                                   int shortcut, float *out, void *stream);
+
+/*
+ * The graph of relations, natively (ABI 8): construct_relation_graph, /root/reference/ultra/rel_model.py:91-143.  The reference
+ * multiplies the (2R x N) and (N x 2R) incidence matrices of the graph with inverse edges four ways -- Eh^T Eh, Et^T Et, Eh^T Et,
+ * Et^T Eh -- and keeps the INDICES of each product (`block.coalesce().indices()`, :131-139): relations r1, r2 get an edge of
+ * type 0 (head-head), 1 (tail-tail), 2 (head-tail), 3 (tail-head) iff some entity is the head / tail of an r1 edge and the
+ * head / tail of an r2 edge.  Here, from the per-entity lists of DISTINCT incident relations:
+ *   head_ptr int32 [n_node + 1], head_rel int32 [head_ptr[n_node]]   relations entity e is the head of (any order inside e)
+ *   tail_ptr, tail_rel                                               ... the tail of
+ *   marks uint8 [4][n_rel][n_rel], 4-byte aligned, written completely: marks[type][r1][r2] = 1 iff that edge exists
+ * One wave per entity marks the pairs of its lists with plain byte stores of the same value (no atomics, nothing to order).
+ * `marks[type].nonzero()` is the block's index list in the reference's (row, column) order.  n_rel <= 32 768.
+ */
+int ultra_relation_graph_marks(const int32_t *head_ptr, const int32_t *head_rel, const int32_t *tail_ptr, const int32_t *tail_rel,
+                               int64_t n_node, int64_t n_rel, uint8_t *marks, void *stream);
 
 /*
  * On-box calibration for the HBM roofline line of bench.py ("confirm on the box with a copy / gather

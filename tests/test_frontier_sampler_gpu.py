@@ -268,6 +268,36 @@ def test_filtered_rank_from_keys_equals_dense_mask_ranking():
     assert torch.equal(UF.filtered_rank(pred.flatten(0, 1), target.flatten(), ptr, node).view(-1, 2), want)
 
 
+def test_filtered_rank_over_many_candidates_counts_in_slices():
+    """Rows of more than 64 K candidates are counted by several workgroups each (one launch writes 1 - filtered count, one adds
+    the slices with integer atomics): the same int64 ranks as the dense-mask formula (ultra/task.py:307-315), ragged last slice,
+    ties, a strided (B, 2, N) view and the unfiltered form included."""
+    from ultra_torchdrug_amd import functional as UF
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    dev = _dev()
+    n, r = 3 * 32768 + 4321, 7
+    tr, n, r = synthetic_triples((n, 40000, r), 6, alpha=0.0)
+    tr[:3000, 0], tr[:3000, 2] = 11, 2                       # one (head, relation) with thousands of known tails
+    graph = Graph(torch.from_numpy(tr).to(dev), num_node=n, num_relation=r)
+    batch = _t(tr[[0, 5, 2999, 3500, 39999]])
+    h, t, rel = batch.t()
+    gen = torch.Generator(device=dev).manual_seed(3)
+    pred = (torch.randn(5, 2, n, device=dev, generator=gen) * 8).round() / 8
+    for side, (anchor, target) in enumerate(((h, t), (t, h))):
+        keys = graph.completion_keys(side)
+        got = UF.filtered_rank_keys(pred[:, side], target, keys, anchor, rel, r, n)
+        pos = pred[:, side].gather(1, target.unsqueeze(1))
+        mask = torch.ones(5, n, dtype=torch.bool, device=dev)
+        for q in range(5):
+            known = graph.edge_list[(graph.edge_list[:, side] == anchor[q]) & (graph.edge_list[:, 2] == rel[q]), 1 - side]
+            mask[q, known] = False
+        want = ((pos <= pred[:, side]) & mask).sum(-1) + 1
+        assert torch.equal(got, want), side
+        assert torch.equal(UF.filtered_rank_keys(pred[:, side], target, None, anchor, rel, r, n), (pos <= pred[:, side]).sum(-1) + 1)
+        assert torch.equal(UF.filtered_rank_keys(pred[:, side], target, keys, anchor, rel, r, n), got)        # replay: same output buffer pattern
+
+
 def test_strict_negatives_from_keys_equal_the_reference_sampler():
     """Same uniform numbers in, same negatives out as mask.nonzero() + variadic_sample (task.py:102-118)."""
     from ultra_torchdrug_amd import functional as UF

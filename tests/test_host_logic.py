@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.ultra_rspmm_abi_version() == version == _lib.ABI_VERSION
     assert lib.ultra_rspmm_status_string(1).decode().startswith("unknown sum/mul")
     import ctypes
-    assert ctypes.sizeof(_lib.UltraSegments) == 22 * 8          # struct layout of the header (ABI 7: + dense, dense_rows, dense_cols, packed_dead)
+    assert ctypes.sizeof(_lib.UltraSegments) == 23 * 8 == lib.ultra_segments_bytes()     # (ABI 8: + the struct_bytes | abi_version fence)
 
 
 def test_library_exports_nothing_but_the_header():

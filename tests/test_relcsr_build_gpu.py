@@ -95,3 +95,25 @@ def test_native_builder_rejects_short_workspace():
                                    chunks.data_ptr(), 16, long_rows.data_ptr(), 4, None, 16, counts, temp.data_ptr(), 64,
                                    None)
     assert status != 0 and b"workspace" in lib.ultra_rspmm_status_string(status).lower()
+
+
+def test_native_relation_graph_equals_the_reference_products():
+    """construct_relation_graph (ultra/rel_model.py:91-143) on the device -- ultra_relation_graph_marks over the entities'
+    distinct relation lists -- gives the edge list of the four sparse incidence products (the ATen path, run here on a CPU copy
+    of the graph): same edges, same order."""
+    from ultra_torchdrug_amd.data import synthetic_triples
+    from ultra_torchdrug_amd.graph import Graph
+    from ultra_torchdrug_amd.rel_model import construct_relation_graph
+    dev = torch.device("cuda:0")
+    shapes = [((300, 2000, 6), 1.0), ((2034, 32888, 42), 1.0), ((14541, 272115, 237), 1.0), ((5000, 3000, 300), 0.0),
+              ((50, 40, 70), 0.0)]
+    for shape, alpha in shapes:
+        tr, n, r = synthetic_triples(shape, 5, alpha=alpha)
+        cpu = Graph(torch.from_numpy(tr), num_node=n + 3, num_relation=r + 2)          # isolated entities, unused relations
+        want = construct_relation_graph(cpu)
+        got = construct_relation_graph(cpu.to(dev))
+        assert got.num_node == want.num_node == 2 * (r + 2) and got.num_relation == 4
+        assert torch.equal(got.edge_list.cpu(), want.edge_list), shape
+    empty = Graph(torch.zeros(0, 3, dtype=torch.long), num_node=5, num_relation=3)
+    assert construct_relation_graph(empty.to(dev)).num_edge == 0
+

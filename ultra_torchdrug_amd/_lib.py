@@ -9,15 +9,19 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ULTRA_RSPMM_LIB: load another build of the same ABI (kernel A/B runs, tools/kbench.py)
 LIB_PATH = os.environ.get("ULTRA_RSPMM_LIB") or os.path.join(_HERE, "libultra_rspmm.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 SUM_OPS = {"add": 0, "min": 1, "max": 2}
 MUL_OPS = {"mul": 0, "add": 1}
 
 
 class UltraSegments(ctypes.Structure):
-    """``struct ultra_segments`` of include/ultra_rspmm.h (device pointers as integers)."""
+    """``struct ultra_segments`` of include/ultra_rspmm.h (device pointers as integers).  A new instance carries the fence
+    of ABI 8: ``struct_bytes`` = the size of THIS declaration, ``abi_version`` = the version this binding was written for;
+    the library refuses a struct whose two leading fields are not its own (``ULTRA_ERR_ABI``)."""
     _fields_ = [
+        ("struct_bytes", ctypes.c_uint32),
+        ("abi_version", ctypes.c_uint32),
         ("n_rows", ctypes.c_int64),
         ("n_edges", ctypes.c_int64),
         ("row", ctypes.c_void_p),
@@ -42,9 +46,17 @@ class UltraSegments(ctypes.Structure):
         ("packed_dead", ctypes.c_void_p),
     ]
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if not self.struct_bytes:
+            self.struct_bytes = ctypes.sizeof(type(self))
+        if not self.abi_version:
+            self.abi_version = ABI_VERSION
+
 
 EXPORTS = (
     "ultra_rspmm_abi_version",
+    "ultra_segments_bytes",
     "ultra_rspmm_status_string",
     "ultra_rspmm_last_hip_error",
     "ultra_rspmm_device_info",
@@ -101,6 +113,7 @@ EXPORTS = (
     "ultra_relcsr_plan",
     "ultra_relcsr_dense_bytes",
     "ultra_relcsr_dense",
+    "ultra_relation_graph_marks",
     "ultra_calibrate_gather_f32",
     "ultra_first_layer_sparse_train_f32",
     "ultra_first_layer_epilogue_backward_workspace",
@@ -139,6 +152,10 @@ def load():
     seg = ctypes.POINTER(UltraSegments)
     lib.ultra_rspmm_abi_version.restype = i32
     lib.ultra_rspmm_abi_version.argtypes = []
+    lib.ultra_relation_graph_marks.restype = i32
+    lib.ultra_relation_graph_marks.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp]
+    lib.ultra_segments_bytes.restype = sz
+    lib.ultra_segments_bytes.argtypes = []
     lib.ultra_rspmm_status_string.restype = ctypes.c_char_p
     lib.ultra_rspmm_status_string.argtypes = [i32]
     lib.ultra_rspmm_last_hip_error.restype = i32
@@ -276,6 +293,9 @@ def load():
     lib.ultra_calibrate_gather_f32.argtypes = [vp, i64, vp, i64, vp, ctypes.POINTER(i64), vp]
     if lib.ultra_rspmm_abi_version() != ABI_VERSION:
         raise UltraLibraryError("ABI mismatch: library %d, binding %d" % (lib.ultra_rspmm_abi_version(), ABI_VERSION))
+    if lib.ultra_segments_bytes() != ctypes.sizeof(UltraSegments):
+        raise UltraLibraryError("struct ultra_segments: library %d bytes, binding %d bytes"
+                                % (lib.ultra_segments_bytes(), ctypes.sizeof(UltraSegments)))
     _lib = lib
     return lib
 

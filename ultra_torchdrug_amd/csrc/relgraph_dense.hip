@@ -549,6 +549,7 @@ size_t ultra_relcsr_dense_bytes(int64_t n_rows, int64_t n_cols, int kind) {
 
 int ultra_relcsr_dense(const ultra_segments *plan, int64_t n_rows, int64_t n_cols, int kind, uint32_t *dense, void *stream) {
     if (plan == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (plan->struct_bytes != (uint32_t)sizeof(ultra_segments) || plan->abi_version != (uint32_t)ULTRA_RSPMM_ABI_VERSION) return ULTRA_ERR_ABI;
     if (plan->n_edges < 0 || plan->n_edges > 0x7fffffffLL) return ULTRA_ERR_BAD_SHAPE;
     if (plan->n_edges > 0 && (plan->row == nullptr || plan->node_a == nullptr || plan->rel == nullptr)) return ULTRA_ERR_NULL_POINTER;
     const size_t bytes = ultra_relcsr_dense_bytes(n_rows, n_cols, kind);
@@ -571,7 +572,8 @@ int ultra_relcsr_dense(const ultra_segments *plan, int64_t n_rows, int64_t n_col
 }
 
 int ultra_dense_layer_supported(const ultra_segments *fwd, int64_t n_query) {
-    if (fwd == nullptr || fwd->dense == nullptr || fwd->weight != nullptr || n_query <= 0) return 0;
+    if (fwd == nullptr || fwd->struct_bytes != (uint32_t)sizeof(ultra_segments) || fwd->abi_version != (uint32_t)ULTRA_RSPMM_ABI_VERSION) return 0;
+    if (fwd->dense == nullptr || fwd->weight != nullptr || n_query <= 0) return 0;
     if (fwd->dense_rows != fwd->n_rows || fwd->dense_rows != fwd->dense_cols) return 0;        // a layer maps the nodes onto themselves
     const long long F = n_query * 64;
     return (F * 4 < (1LL << 24) && fwd->dense_cols * F * 4 < (1LL << 31)) ? 1 : 0;
@@ -581,6 +583,8 @@ int ultra_dense_layer_forward_f32(const ultra_segments *fwd, const float *relati
                                   const int32_t *boundary_node, const float *boundary_value, int64_t n_query, const float *weight,
                                   const float *bias, const float *ln_weight, const float *ln_bias, float ln_eps, int relu,
                                   int shortcut, float *out, void *stream) {
+    if (fwd != nullptr && (fwd->struct_bytes != (uint32_t)sizeof(ultra_segments) || fwd->abi_version != (uint32_t)ULTRA_RSPMM_ABI_VERSION))
+        return ULTRA_ERR_ABI;
     if (!ultra_dense_layer_supported(fwd, n_query)) return ULTRA_ERR_BAD_SHAPE;
     if (relation == nullptr || input == nullptr || boundary_node == nullptr || boundary_value == nullptr || weight == nullptr ||
         bias == nullptr || out == nullptr)

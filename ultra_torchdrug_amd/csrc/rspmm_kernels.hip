@@ -1084,8 +1084,15 @@ int launch_ops(const KParams &p, int sum_op, int mul_op, bool unit_w, bool rel_l
     return ULTRA_ERR_BAD_OP;
 }
 
+// The fence of the boundary (ABI 8): the caller's struct must be THIS header's, field for field.  Only the two leading
+// fields are read before that is known.
+inline bool segments_abi_ok(const ultra_segments *s) {
+    return s->struct_bytes == (uint32_t)sizeof(ultra_segments) && s->abi_version == (uint32_t)ULTRA_RSPMM_ABI_VERSION;
+}
+
 int check_segments(const ultra_segments *s) {
     if (s == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (!segments_abi_ok(s)) return ULTRA_ERR_ABI;
     if (s->n_rows < 0 || s->n_edges < 0 || s->n_chunks < 0 || s->n_pieces < 0 || s->n_long_rows < 0)
         return ULTRA_ERR_BAD_SHAPE;
     if (s->n_rows > 0x7fffffffLL || s->n_edges > 0x7fffffffLL || s->n_chunks > 0x7fffffffLL) return ULTRA_ERR_BAD_SHAPE;
@@ -1529,6 +1536,8 @@ extern "C" {
 
 int ultra_rspmm_abi_version(void) { return ULTRA_RSPMM_ABI_VERSION; }
 
+size_t ultra_segments_bytes(void) { return sizeof(ultra_segments); }
+
 const char *ultra_rspmm_status_string(int status) {
     switch (status) {
         case ULTRA_OK: return "ok";
@@ -1538,6 +1547,7 @@ const char *ultra_rspmm_status_string(int status) {
         case ULTRA_ERR_WORKSPACE: return "workspace is NULL or smaller than ultra_rspmm_workspace_bytes()";
         case ULTRA_ERR_HIP: return "HIP runtime error (see ultra_rspmm_last_hip_error)";
         case ULTRA_ERR_NO_DEVICE: return "no usable HIP device";
+        case ULTRA_ERR_ABI: return "ultra_segments.struct_bytes / abi_version are not this library's (binding written against another include/ultra_rspmm.h)";
         default: return "unknown status";
     }
 }
@@ -1604,7 +1614,7 @@ int ultra_rspmm_profile_next(void *start_event, void *stop_event) {
 }
 
 size_t ultra_rspmm_workspace_bytes(const ultra_segments *seg, int64_t F) {
-    if (seg == nullptr || F <= 0) return 0;
+    if (seg == nullptr || F <= 0 || !segments_abi_ok(seg)) return 0;     // (the call over a foreign struct then fails with ULTRA_ERR_ABI)
     int64_t rows = seg->n_pieces > 0 ? seg->n_pieces : 0;
     // d_relation plan in its dense form: one tile sum per 16 destination nodes and relation type (relgraph_dense.hip)
     if (seg->dense != nullptr && seg->n_rows == 4 && seg->node_b != nullptr) rows = std::max<int64_t>(rows, 4 * ((seg->dense_rows + 15) / 16));
@@ -1615,6 +1625,7 @@ int ultra_rspmm_forward_f32(const ultra_segments *fwd, const float *relation, co
                             float *out, void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_rel, int64_t F,
                             int sum_op, int mul_op, void *stream) {
     if (fwd == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (!segments_abi_ok(fwd)) return ULTRA_ERR_ABI;
     if (fwd->n_rows > 0 && out == nullptr) return ULTRA_ERR_NULL_POINTER;
     if (fwd->n_edges > 0 && (relation == nullptr || input == nullptr)) return ULTRA_ERR_NULL_POINTER;
     KParams p{};
@@ -1660,7 +1671,9 @@ int ultra_rspmm_forward_boundary_f32(const ultra_segments *fwd, const float *rel
                                      const int32_t *boundary_node, const float *boundary_value, int64_t block, float *out,
                                      void *workspace, size_t workspace_bytes, int64_t n_src, int64_t n_rel, int64_t F,
                                      int sum_op, int mul_op, void *stream) {
-    if (fwd == nullptr || boundary_node == nullptr || boundary_value == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (fwd == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (!segments_abi_ok(fwd)) return ULTRA_ERR_ABI;
+    if (boundary_node == nullptr || boundary_value == nullptr) return ULTRA_ERR_NULL_POINTER;
     if (fwd->n_rows > 0 && out == nullptr) return ULTRA_ERR_NULL_POINTER;
     if (fwd->n_edges > 0 && (relation == nullptr || input == nullptr)) return ULTRA_ERR_NULL_POINTER;
     if (block <= 0 || block > 0x7fffffffLL || F <= 0 || F % block != 0) return ULTRA_ERR_BAD_SHAPE;
@@ -1916,6 +1929,7 @@ int ultra_rspmm_backward_accumulate_f32(const ultra_segments *by_src, const ultr
     }
     if (d_relation != nullptr) {
         if (by_rel == nullptr) return ULTRA_ERR_NULL_POINTER;
+        if (!segments_abi_ok(by_rel)) return ULTRA_ERR_ABI;
         if (by_rel->n_edges > 0 && by_rel->node_b == nullptr) return ULTRA_ERR_NULL_POINTER;
         KParams p{};
         p.relation = relation;
@@ -1950,6 +1964,7 @@ int ultra_rspmm_backward_active_f32(const ultra_segments *by_src, const ultra_se
     }
     if (d_relation != nullptr) {
         if (by_rel == nullptr) return ULTRA_ERR_NULL_POINTER;
+        if (!segments_abi_ok(by_rel)) return ULTRA_ERR_ABI;
         if (by_rel->n_edges > 0 && by_rel->node_b == nullptr) return ULTRA_ERR_NULL_POINTER;
         KParams p{};
         p.relation = relation; p.input = input; p.grad = output_grad; p.out = d_relation;

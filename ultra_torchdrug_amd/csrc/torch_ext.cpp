@@ -176,6 +176,8 @@ OwnedPlan make_plan(const Tensor &row, const Tensor &node_a, const Tensor &node_
     Tensor weight_kept;
     if (weight.defined()) weight_kept = at::cat({weight, at::ones({slack}, weight.options())});
     ultra_segments &s = plan.seg;
+    s.struct_bytes = (uint32_t)sizeof(ultra_segments);
+    s.abi_version = (uint32_t)ULTRA_RSPMM_ABI_VERSION;
     s.n_rows = n_rows;
     s.n_edges = E;
     s.row = row.data_ptr<int>();

@@ -739,6 +739,34 @@ def score_candidates(hidden, query, t_index, w1, b1, w2, b2):
     return _ScoreRows.apply(hidden, query, t_index, w1, b1, w2, b2)
 
 
+def relation_graph_blocks(edge_list, n_node, n_rel):
+    """The four blocks of ``construct_relation_graph`` (/root/reference/ultra/rel_model.py:99-143) for a graph WITH inverse
+    edges on the device: bool ``(4, n_rel, n_rel)``, ``[type, r1, r2]`` True iff some entity is the head / tail of an ``r1``
+    edge and the head / tail of an ``r2`` edge (type 0 hh, 1 tt, 2 ht, 3 th) -- the index pattern of the reference's four sparse
+    incidence products, from ``ultra_relation_graph_marks`` (one wave per entity) instead of four spgemm calls over 2R rows of
+    ~E / 2R entries each (117 s on S-stress; this: two key sorts + one launch).  One-off preprocessing: allocates and reads
+    the host once (the list lengths)."""
+    if not edge_list.is_cuda or edge_list.dtype != torch.int64 or edge_list.dim() != 2 or edge_list.shape[1] != 3:
+        raise RuntimeError("relation_graph_blocks: edge_list must be int64 (E, 3) on the HIP device")
+    n_node, n_rel = int(n_node), int(n_rel)
+    dev = edge_list.device
+    lists = []
+    nodes = torch.arange(n_node + 1, device=dev) * n_rel
+    for col in (0, 1):
+        key = torch.unique(edge_list[:, col] * n_rel + edge_list[:, 2])          # sorted DISTINCT (entity, relation) pairs
+        if key.numel() >= 2 ** 31:
+            raise RuntimeError("relation_graph_blocks: more than 2^31 (entity, relation) pairs")
+        ptr = torch.searchsorted(key, nodes).to(torch.int32)
+        rel = (key % n_rel).to(torch.int32)
+        lists += [ptr, rel]
+    marks = torch.empty(4, n_rel, n_rel, dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.ultra_relation_graph_marks(lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr(), lists[3].data_ptr(),
+                                                  n_node, n_rel, marks.data_ptr(), _stream()))
+    return marks.bool()
+
+
 def relation_stack_inputs(weights, h_index):
     """Inputs of the relation stack's first layer in one launch (``ultra_relation_stack_inputs``): ``weights``: the layers'
     relation embeddings, each fp32 ``(R4, 64)``; ``h_index`` int64 ``(Q,)``.  Returns ``(tables (L, R4, Q * 64), ones (Q, 64),

@@ -25,6 +25,16 @@ def construct_relation_graph(graph):
     graph = graph.undirected(add_inverse=True)
     device = graph.device
     n_rel, n_node = graph.num_relation, graph.num_node
+    if graph.edge_list.is_cuda and 0 < n_rel <= 32768:
+        # on the MI355X: the same four index patterns from one native launch over the entities' relation lists
+        # (functional.relation_graph_blocks); nonzero() lists a block in the (row, column) order coalesce() gives
+        from . import functional
+        blocks = functional.relation_graph_blocks(graph.edge_list, n_node, n_rel)
+        edges = []
+        for etype in range(4):
+            idx = blocks[etype].nonzero()
+            edges.append(torch.cat([idx, torch.full((idx.shape[0], 1), etype, dtype=torch.long, device=device)], dim=1))
+        return Graph(torch.cat(edges, dim=0), num_node=n_rel, num_relation=4)
 
     def incidence(col):
         pairs = graph.edge_list[:, [col, 2]].unique(dim=0)                     # (entity, relation)
