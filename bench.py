@@ -221,28 +221,38 @@ def latest_profile(pattern):
 
 
 def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel=500):
-    """Config 5 at size: S-stress -- uniform triples + inverse edges => E = 100 M, R = 1 000, 64d,
-    B = 1.  The gathered matrix (2.56 GB) cannot live in any cache: the HBM roofline of the operator."""
-    import ultra_torchdrug_amd as U
+    """Config 5 at size: S-stress -- uniform triples + inverse edges => E = 100 M, R = 1 000, 64d.
+    (i) the operator at B = 1 (the gathered matrix, 2.56 GB, cannot live in any cache: the HBM roofline of the path) and at
+    B = 4 (`b4`: 1-KiB gathers, 64 lanes per row); (ii) what BASELINE calls this config -- INFERENCE: the whole `predict` of the
+    shipped 6 x 64d model (relation stack, 6 entity layers with their epilogues, score head) + the filtered rank, at B = 1 and
+    B = 4 triples (2 B queries), with one middle layer kernel by kernel; (iii) the CPU restatement on the same graph (`cpu`)."""
     from ultra_torchdrug_amd import functional as UF
-    gen = torch.Generator(device=dev).manual_seed(1024)
-    h = torch.randint(0, n_node, (n_triple,), device=dev, generator=gen)
-    t = torch.randint(0, n_node, (n_triple,), device=dev, generator=gen)
-    r = torch.randint(0, n_base_rel, (n_triple,), device=dev, generator=gen)
+    from ultra_torchdrug_amd.data import stress_task
     t0 = time.perf_counter()
-    csr = U.RelCSR(torch.cat([t, h]), torch.cat([h, t]), torch.cat([r, r + n_base_rel]), None, n_node, n_node,
-                   2 * n_base_rel)
+    task, gen = stress_task(dev, n_node, n_triple, n_base_rel)
+    torch.cuda.synchronize()
+    task_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    und = task.model._undirected(task.fact_graph)
+    csr = und.relcsr
     plan = csr.fwd
+    _ = csr.frontier_index
+    _ = task.rel_graphs[0].relcsr.fwd
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
-    del h, t, r
-    F, R = 64, 2 * n_base_rel
-    x = torch.randn(n_node, F, device=dev, generator=gen)
-    relation = torch.randn(R, F, device=dev, generator=gen)
-    for _ in range(3):
-        UF.rspmm_forward(csr, relation, x, "add", "mul")
+    R = 2 * n_base_rel
+    E = csr.n_edges
     events = HipEvents(lib)
-    ms, n = timed_kernel(lib, events, lambda: UF.rspmm_forward(csr, relation, x, "add", "mul"), 12)
+
+    def operator(F, reps):
+        x = torch.randn(n_node, F, device=dev, generator=gen)
+        relation = torch.randn(R, F, device=dev, generator=gen)
+        for _ in range(3):
+            UF.rspmm_forward(csr, relation, x, "add", "mul")
+        ms, n = timed_kernel(lib, events, lambda: UF.rspmm_forward(csr, relation, x, "add", "mul"), reps)
+        return x, relation, ms, n
+
+    x, relation, ms, n = operator(64, 12)
     # the chunked kernel the plan would run without the row-per-group kernel (A/B of the same launch)
     lib.ultra_rspmm_force_general_path(8)
     try:
@@ -251,13 +261,23 @@ def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel
         ms_chunked, _ = timed_kernel(lib, events, lambda: UF.rspmm_forward(csr, relation, x, "add", "mul"), 6)
     finally:
         lib.ultra_rspmm_force_general_path(0)
-    E = csr.n_edges
-    algo = bytes_algo(E, n_node, R, F)
+    algo = bytes_algo(E, n_node, R, 64)
     kernel = "rowgroup_kernel<add,mul,unit_w,624 of 1000 relation rows from LDS>" if plan.row_ptr is not None and plan.n_pieces == 0 \
         else "packed_kernel<FWD,add,mul,unit_w,VAR 2>"
     tj, tsrc = latest_profile("traffic_stress.json")
     achieved = algo / (ms * 1e-3) / 1e9
     cal = box_calibration(dev, lib, x, plan.node_a[:E])
+    del x, relation
+    _, _, ms4, n4 = operator(256, 6)
+    torch.cuda.empty_cache()
+    algo4 = bytes_algo(E, n_node, R, 256)
+    b4 = {"bound": "hbm", "achieved": algo4 / (ms4 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": algo4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms4, "algorithmic_bytes": algo4, "launches_timed": n4,
+          "workload": "S-stress B=4 F=256 (input %.2f GB; one 1-KiB gather per edge, 64 lanes per row)" % (n_node * 256 * 4 / 1e9),
+          "edges_per_s": 4 * E / (ms4 * 1e-3)}
+    inference = stress_inference(task, csr, gen, n_node, n_base_rel)
+    inference["task_build_s"] = task_s
+    cpu = stress_cpu_baseline(csr, plan, n_node, R)
     # the keys the driver's record keeps come first: the contract's six, then what THIS box delivers ("confirm on the
     # box with a copy / gather calibration, report both") -- `frac` moves 0.65 <-> 0.70 with the box, `frac_of_gather` says how much
     # of that is the box and how much the kernel
@@ -266,10 +286,143 @@ def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel
             "copy_GBps": cal["copy_GBps"], "gather_GBps": cal["gather_GBps"], "frac_of_gather": achieved / cal["gather_GBps"],
             "frac_of_copy": achieved / cal["copy_GBps"],
             "kernel_ms": ms, "algorithmic_bytes": algo, "bytes_per_unit": algo / E, "launches_timed": n,
-            "workload": "S-stress N=%d E=%d R=%d B=1 F=64 (input %.2f GB)" % (n_node, E, R, n_node * F * 4 / 1e9),
+            "workload": "S-stress N=%d E=%d R=%d B=1 F=64 (input %.2f GB)" % (n_node, E, R, n_node * 64 * 4 / 1e9),
             "kernel": kernel, "edges_per_s": E / (ms * 1e-3), "chunked_kernel_ms": ms_chunked, "plan_build_s": build_s,
             "traffic_source": tsrc, "calibration": cal["note"],
-            "timed": "HIP events recorded by the library around the kernel, on the kernel's stream, %d launches" % n}
+            "timed": "HIP events recorded by the library around the kernel, on the kernel's stream, %d launches" % n,
+            "b4": b4, "inference": inference, "cpu": cpu}
+
+
+def stress_inference(task, csr, gen, n_node, n_base_rel):
+    """BASELINE config 5 as INFERENCE (/root/reference/ultra/task.py:228-263, ultra/model.py:101-143,182-194): `predict` + filtered
+    rank on S-stress, eager (every kernel runs for milliseconds: nothing to gain from a hipGraph), B = 1 and B = 4 triples; and
+    the sequence `TransferNBFNet.score_both_sides` runs, op by op between stream events, at B = 1."""
+    from ultra_torchdrug_amd import backend
+    dev = csr.device
+    ops = backend.get()
+    E, R = csr.n_edges, 2 * n_base_rel
+    out = {}
+
+    def draw(B):
+        return torch.stack([torch.randint(0, n_node, (B,), device=dev, generator=gen),
+                            torch.randint(0, n_node, (B,), device=dev, generator=gen),
+                            torch.randint(0, n_base_rel, (B,), device=dev, generator=gen)], dim=1)
+
+    with torch.no_grad():
+        for B in (1, 4):
+            batch = draw(B)
+            pred = task.predict(batch)
+            ranks = task.rank_batch(batch, pred)
+            torch.cuda.synchronize()
+            p_ms, r_ms = [], []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pred = task.predict(batch)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                task.rank_batch(batch, pred)
+                torch.cuda.synchronize()
+                p_ms.append(1e3 * (t1 - t0)); r_ms.append(1e3 * (time.perf_counter() - t1))
+            tag = "b%d" % B
+            out[tag] = {"triples": B, "queries": 2 * B, "F": 128 * B, "predict_ms": float(np.median(p_ms)),
+                        "filtered_rank_ms": float(np.median(r_ms)), "ranks_first": ranks[0].tolist(),
+                        "scores_finite": bool(torch.isfinite(pred).all()),
+                        "entity_edge_messages_per_s": 5 * E * 2 * B / (float(np.median(p_ms)) * 1e-3),
+                        "counts": "5 full entity layers x E x 2B queries (the first layer visits the boundary nodes' out-edges "
+                                  "only) over the whole predict: relation stack, epilogues and score head are in the time"}
+            del pred
+        torch.cuda.empty_cache()
+        # ---- B = 1, op by op (what score_both_sides runs)
+        model = task.model
+        batch = draw(1)
+        rel_rep = task.relation_representations(batch[:, 2])[0]
+        stack = model._fast_stack()
+        anchor, anchor32, relation, query = ops.prepare_queries(batch, rel_rep, n_base_rel)
+        tables = ops.relation_project(rel_rep, [entry["project"] for entry in stack], repeat=2)
+        boundary = (anchor32, query)
+        marks = []
+
+        def mark(name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+
+        for rep in range(2):                                           # the second pass is the measured one
+            marks.clear()
+            mark("start")
+            w, b, g, beta, eps, relu = stack[0]["combine"]
+            hidden = ops.first_layer_forward(csr, tables[0], boundary, w, b, g, beta, eps, relu, model.short_cut)
+            if hidden is None:
+                update = ops.rspmm_frontier(csr, tables[0], boundary).view(n_node, 2, 64)
+                hidden = ops.combine_forward(None, update, w, b, g, beta, eps, relu, model.short_cut, reuse_update=True,
+                                             input_boundary=boundary)
+            mark("first_layer")
+            for i in range(1, len(stack)):
+                w, b, g, beta, eps, relu = stack[i]["combine"]
+                update = ops.rspmm_forward(csr, tables[i], hidden.flatten(1), "add", "mul", boundary=boundary)
+                mark("rspmm_%d" % (i + 1))
+                hidden = ops.combine_forward(hidden, update.view(n_node, 2, 64), w, b, g, beta, eps, relu, model.short_cut,
+                                             reuse_update=True)
+                mark("epilogue_%d" % (i + 1))
+            first, second = model.mlp.layers
+            ops.score_all_entities(hidden, query, first.weight, first.bias, second.weight, second.bias)
+            mark("score_head")
+            torch.cuda.synchronize()
+        steps = {name: marks[k - 1][1].elapsed_time(e) for k, (name, e) in enumerate(marks) if k > 0}
+        rspmm = float(np.median([v for k, v in steps.items() if k.startswith("rspmm_")]))
+        epi = float(np.median([v for k, v in steps.items() if k.startswith("epilogue_")]))
+        F = 128
+        layer_bytes = bytes_algo(E, n_node, R, F) + 3 * n_node * F * 4
+        out["layer_b1"] = {"first_layer_ms": steps["first_layer"], "rspmm_ms": rspmm, "epilogue_ms": epi,
+                           "score_head_ms": steps["score_head"], "steps_ms": steps,
+                           "layer_algorithmic_bytes": layer_bytes,
+                           "frac_of_hbm_peak_whole_layer": layer_bytes / ((rspmm + epi) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "frac_of_hbm_peak_rspmm": bytes_algo(E, n_node, R, F) / (rspmm * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "frac_of_hbm_peak_epilogue": 3 * n_node * F * 4 / (epi * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "bytes": "one layer = rspmm's algorithmic bytes at F = 128 (E (4F + 12) + 4NF + 4RF + 4(N + 1)) + the "
+                                    "epilogue's 3 N F 4 (input and update rows in, output rows out); stream events on the launch "
+                                    "stream between eager calls, medians over layers 2-6"}
+    return out
+
+
+def stress_cpu_baseline(csr, plan, n_node, n_rel, budget_s=20.0):
+    """SURVEY 8d's second CPU leg: the restatement of the torchdrug CPU algorithm (oracle/rspmm_oracle.c) on S-stress, B = 1,
+    on this host's cores -- only when the host has the memory for it (the operands are ~8 GB).  The coalesced CSR comes from the
+    device's plan (sorting 100 M keys on the host is not what is timed)."""
+    try:
+        avail = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")) / 1e6
+    except (OSError, StopIteration, ValueError):
+        avail = 0.0
+    if avail < 24.0:
+        return {"skipped": "host reports %.1f GB available (< 24 GB)" % avail}
+    from oracle import oracle as O
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    O.build()
+    try:
+        forward = O.native_forward_fn()
+    except Exception:
+        forward = O.rspmm_forward
+    E = csr.n_edges
+    row_ptr = plan.row_ptr if plan.row_ptr is not None else torch.searchsorted(plan.row[:E], torch.arange(n_node + 1, dtype=torch.int32, device=plan.row.device))
+    host = O.CSR(row_ptr.cpu().numpy().astype(np.int64), plan.node_a[:E].cpu().numpy().astype(np.int64),
+                 plan.rel[:E].cpu().numpy().astype(np.int64), np.ones(E, dtype=np.float32), n_node, n_node, n_rel)
+    rng = np.random.default_rng(1024)
+    x = rng.standard_normal((n_node, 64), dtype=np.float32)
+    relation = rng.standard_normal((n_rel, 64), dtype=np.float32)
+    if getattr(forward, "set_threads", None) is not None:
+        forward.set_threads(cores)
+    forward(host, relation, x, "add", "mul")
+    times, t_start = [], time.perf_counter()
+    while len(times) < 5 and time.perf_counter() - t_start < budget_s:
+        t0 = time.perf_counter()
+        forward(host, relation, x, "add", "mul")
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": E / med, "unit": "edges aggregated/s", "cores": cores, "kind": "port", "seconds_per_call": med,
+            "algorithmic_GBps": bytes_algo(E, n_node, n_rel, 64) / med / 1e9, "host_available_GB": avail,
+            "sample": "%d x one rspmm forward (add,mul) on S-stress, E=%d, F=64 (B=1), %d OpenMP threads; oracle/rspmm_oracle.c"
+                      % (len(times), E, cores)}
 
 
 def box_calibration(dev, lib, table, index):
@@ -535,6 +688,10 @@ def flat_config_keys(configs):
     put("cfg4_eager_step_ms", 4, "eager_step_ms")
     put("cfg5_frac", 5, "frac_of_hbm_peak")
     put("cfg5_fwd_ms", 5, "operator_fwd_ms")
+    put("cfg5_predict_ms", 5, "predict_ms")
+    put("cfg5_predict_ms_b4", 5, "predict_ms_b4")
+    put("cfg5_whole_layer_frac", 5, "frac_of_hbm_peak_whole_layer")
+    put("cfg5_b4_frac", 5, "operator_b4_frac")
     return flat
 
 
@@ -644,14 +801,17 @@ def pretrain_timing(dev, seed, rank, world, ranks, quick):
         shared = torch.Generator().manual_seed(seed)                 # the same draws on every rank
         same = draw(shared, n_steps)
         loop(same[:3], True)
-        with_comm, _, _ = loop(same, True)
-        without, _, _ = loop(same, False)                            # LAST: the ranks' weights drift apart from here on
+        with_comm, mine_with, _ = loop(same, True)
+        without, mine_without, _ = loop(same, False)                 # LAST: the ranks' weights drift apart from here on
         modes = graphed.modes
         mode = "/".join(sorted(set(modes.values())))
         # every rank and context should be in the same mode (a capture whose phased backward does not verify drops to
         # "after" with a warning, possibly on one rank only: the collectives still match, the overlap is lost there)
         code = float(sum({"phased": 0, "after": 1, "in_graph": 2, "single": 3}.get(m, 4) * 10 ** i for i, m in enumerate(modes[k] for k in sorted(modes))))
         agree = ranks.max([code])[0] == -ranks.max([-code])[0] and len(set(modes.values())) == 1
+        names = ("phased", "after", "in_graph", "single", "?")
+        per_rank_modes = ["/".join(names[int(c) // 10 ** i % 10] for i in range(len(modes))) for c in ranks.gather(code)]
+        per_rank_exposed = [1e3 * v / n_steps for v in ranks.gather(mine_with - mine_without)]
         out.update({"step_modes": modes, "step_modes_agree": bool(agree), "collective_backend": dist.get_backend(),
                     "gradient_allreduce": "engine.GradientReducer: %d buckets in %d groups (one all-reduce per group), %d fp32 "
                                           "parameters, %s, side stream; step mode `%s` (phased: 3 captured phases, each phase's group "
@@ -662,7 +822,12 @@ def pretrain_timing(dev, seed, rank, world, ranks, quick):
                     "step_mode": mode,
                     "same_graphs_step_ms_with_allreduce": 1e3 * with_comm / n_steps,
                     "same_graphs_step_ms_without_allreduce": 1e3 * without / n_steps,
-                    "allreduce_exposed_ms_per_step": 1e3 * (with_comm - without) / n_steps})
+                    "allreduce_exposed_ms_per_step": 1e3 * (with_comm - without) / n_steps,
+                    "allreduce_exposed_is": "max-over-ranks wall time of the same K steps with the collectives minus without them "
+                                            "(all ranks on the same graphs: no straggler wait inside the difference)",
+                    "allreduce_exposed_ms_per_step_per_rank": per_rank_exposed,
+                    "step_modes_per_rank": per_rank_modes,
+                    "step_modes_per_rank_order": "contexts %s" % ",".join(sorted(modes))})
         reducer.remove_hooks()
     else:
         eager = []
@@ -1146,10 +1311,18 @@ def main():
         if args.stress:                             # rank 0 of any world: the other ranks wait at the final barrier
             roofline = stress_roofline(dev, lib)
             roofline["l2"] = l2_line
+            inf = roofline["inference"]
             configs.append({"config": 5, "name": "Synthetic KG 10M nodes / 100M edges / 1k relations, 64d inference (HBM-roofline stress)",
                             "shape": roofline["workload"], "operator_fwd_ms": roofline["kernel_ms"],
                             "edges_per_s": roofline["edges_per_s"], "frac_of_hbm_peak": roofline["frac"],
-                            "plan_build_s": roofline["plan_build_s"]})
+                            "plan_build_s": roofline["plan_build_s"],
+                            "predict_ms": inf["b1"]["predict_ms"], "predict_ms_b4": inf["b4"]["predict_ms"],
+                            "filtered_rank_ms": inf["b1"]["filtered_rank_ms"],
+                            "end_to_end_edges_per_s": inf["b1"]["entity_edge_messages_per_s"],
+                            "end_to_end_edges_per_s_b4": inf["b4"]["entity_edge_messages_per_s"],
+                            "layer_breakdown_b1": inf["layer_b1"],
+                            "frac_of_hbm_peak_whole_layer": inf["layer_b1"]["frac_of_hbm_peak_whole_layer"],
+                            "operator_b4_ms": roofline["b4"]["kernel_ms"], "operator_b4_frac": roofline["b4"]["frac"]})
         # ---- `config`: the driver's record keeps about twenty scalars of it, in order, strings cut at ~128 characters (VERDICT r4
         # weak 8: the MRR half of the metric and configs 3-5 fell off the end) -- so the ones a reader needs come first
         flat = flat_config_keys(configs)
@@ -1173,6 +1346,8 @@ def main():
             "cfg4_allreduce_exposed_ms_per_step": flat.get("cfg4_allreduce_exposed_ms_per_step"),
             "cfg5_frac": flat.get("cfg5_frac"),
             "cfg5_fwd_ms": flat.get("cfg5_fwd_ms"),
+            "cfg5_predict_ms": flat.get("cfg5_predict_ms"),
+            "cfg5_whole_layer_frac": flat.get("cfg5_whole_layer_frac"),
             "collective_backend": (dist.get_backend() if world > 1 else "none (one rank)"),
             "ranks_distinct_devices": devices,
             "ms_per_step_block_median": headline_blocks["median_ms"],
@@ -1248,6 +1423,8 @@ def main():
             und_np = {"dst": und.edge_list[:, 1].cpu().numpy(), "src": und.edge_list[:, 0].cpu().numpy(),
                       "rel": und.edge_list[:, 2].cpu().numpy()}
             result["cpu_baseline"] = cpu_baseline(und_np, n_node, R2, Fk)
+            if args.stress and isinstance(roofline.get("cpu"), dict):
+                result["cpu_baseline"]["stress"] = roofline.pop("cpu")
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

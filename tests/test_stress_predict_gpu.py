@@ -1,0 +1,147 @@
+"""BASELINE config 5 as what it is called -- *inference* on S-stress (10 M nodes / 100 M edges / 1 000 relations, 64d): the
+whole `predict` of the shipped 6 x 64d model at size (/root/reference/ultra/task.py:228-263, ultra/model.py:101-143,182-194),
+one triple = 2 queries (tail and head side), F = 128.
+
+The CPU oracle cannot run six layers over 100 M edges in test time, so every layer is held to it where it can be:
+
+* the package's fused sequence (`TransferNBFNet.score_both_sides`) is replayed op by op here -- the same backend calls on the
+  same operands -- and its final scores must be `torch.equal` to `task.predict` (so the per-layer checks below are checks of
+  the product path, not of a look-alike);
+* per layer, 50 000 consecutive destination rows: the oracle's rspmm (sequential order, sources re-labelled) + sparse boundary
+  + `oracle_combine_forward` on the HIP layer's INPUT rows must give the HIP layer's OUTPUT rows bit for bit -- six chained
+  equalities, each at full graph size on the GPU side;
+* one layer's WHOLE output (10 M x 2 x 64) against the reference's own ATen definition (ultra/layer.py:249-255,275-276,358,
+  386-392: gather, multiply, scatter_add, + boundary, Linear, LayerNorm, ReLU; + shortcut, ultra/model.py:126-127) within the
+  summation bound, no oracle in between;
+* the score head on a 50 000-candidate subset against `oracle.score_head_forward`, and the filtered ranks of the two queries
+  against the dense formula of ultra/task.py:307-315 over all 10 M candidates.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_whole_model_inference_on_the_stress_graph(oracle):
+    from ultra_torchdrug_amd import backend
+    from ultra_torchdrug_amd.data import stress_task
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    N, TRIPLES, R_BASE = 10_000_000, 50_000_000, 500
+    task, gen = stress_task(dev, N, TRIPLES, R_BASE)
+    model = task.model
+    ops = backend.get()
+    batch = torch.stack([torch.randint(0, N, (1,), device=dev, generator=gen), torch.randint(0, N, (1,), device=dev, generator=gen),
+                         torch.randint(0, R_BASE, (1,), device=dev, generator=gen)], dim=1)
+    with torch.no_grad():
+        pred = task.predict(batch)                                              # (1, 2, N)
+        assert pred.shape == (1, 2, N) and bool(torch.isfinite(pred).all())
+        assert torch.equal(pred, task.predict(batch)), "two predictions of the same batch differ"
+
+        # ---- the fused sequence op by op (model.score_both_sides), every layer's input and output kept
+        rel_rep = task.relation_representations(batch[:, 2])[0]
+        und = model._undirected(task.fact_graph)
+        csr = und.relcsr
+        assert csr.n_edges > 99_900_000 and und.num_relation == 2 * R_BASE
+        stack = model._fast_stack()
+        anchor, anchor32, relation, query = ops.prepare_queries(batch, rel_rep, R_BASE)
+        tables = ops.relation_project(rel_rep, [entry["project"] for entry in stack], repeat=2)
+        boundary = (anchor32, query)
+        n_query = 2
+        hiddens = []
+        hidden = None
+        for i, entry in enumerate(stack):
+            w, b, g, beta, eps, relu = entry["combine"]
+            if i == 0:
+                hidden = ops.first_layer_forward(csr, tables[0], boundary, w, b, g, beta, eps, relu, model.short_cut)
+                if hidden is None:
+                    update = ops.rspmm_frontier(csr, tables[0], boundary).view(N, n_query, 64)
+                    hidden = ops.combine_forward(None, update, w, b, g, beta, eps, relu, model.short_cut, reuse_update=True,
+                                                 input_boundary=boundary)
+            else:
+                update = ops.rspmm_forward(csr, tables[i], hidden.flatten(1), "add", "mul", boundary=boundary)
+                hidden = ops.combine_forward(hidden, update.view(N, n_query, 64), w, b, g, beta, eps, relu, model.short_cut,
+                                             reuse_update=False)
+            hiddens.append(hidden)
+        first, second = model.mlp.layers
+        scores = ops.score_all_entities(hidden, query, first.weight, first.bias, second.weight, second.bias)      # (2, N)
+        assert torch.equal(scores.view(2, 1, N).transpose(0, 1), pred), "the op-by-op replay is not what predict computes"
+
+        # ---- per layer: the oracle on 50 000 destination rows, from the HIP layer's input rows
+        start = max(0, min(int(anchor[0]) - 25_000, N - 50_000))                # the tail query's boundary node lies inside
+        rows = torch.arange(start, start + 50_000, device=dev)
+        lo = int(torch.searchsorted(csr.dst, rows[0]))
+        hi = int(torch.searchsorted(csr.dst, rows[-1] + 1))
+        sub_dst, sub_src, sub_rel = csr.dst[lo:hi] - rows[0], csr.src[lo:hi], csr.rel_id[lo:hi]
+        assert int(torch.bincount(sub_dst).max()) <= csr.piece_len              # unsplit rows: the reference order
+        uniq, inverse = torch.unique(sub_src, return_inverse=True)
+        csr_o = oracle.coalesce_csr(sub_dst.cpu().numpy(), inverse.cpu().numpy(), sub_rel.cpu().numpy(), None, len(rows),
+                                    len(uniq), 2 * R_BASE)
+        a_np, q_np = anchor32.cpu().numpy(), query.cpu().numpy()
+        bound_rows = np.zeros((len(rows), n_query, 64), dtype=np.float32)
+        for qi in range(n_query):
+            local = int(a_np[qi]) - int(rows[0])
+            if 0 <= local < len(rows):
+                bound_rows[local, qi] = q_np[qi]
+        zeros_in = np.zeros((len(uniq), n_query * 64), dtype=np.float32)
+        for i, entry in enumerate(stack):
+            w, b, g, beta, eps, relu = (t.cpu().numpy() if torch.is_tensor(t) else t for t in entry["combine"])
+            if i == 0:                                                          # input = the boundary itself
+                x_src = zeros_in.copy().reshape(len(uniq), n_query, 64)
+                for qi in range(n_query):
+                    hit = (uniq == int(a_np[qi])).nonzero().flatten()
+                    if len(hit):
+                        x_src[int(hit[0]), qi] = q_np[qi]
+                x_src = x_src.reshape(len(uniq), -1)
+                in_rows = bound_rows
+            else:
+                x_src = hiddens[i - 1][uniq].flatten(1).cpu().numpy()
+                in_rows = hiddens[i - 1][rows].cpu().numpy()
+            upd = oracle.rspmm_forward(csr_o, tables[i].cpu().numpy(), x_src, "add", "mul", piece=0)
+            upd = upd.reshape(len(rows), n_query, 64) + bound_rows              # layer.py:358 (adding +0 elsewhere: exact)
+            want = oracle.combine_forward(np.ascontiguousarray(in_rows), np.ascontiguousarray(upd), w, b, g, beta, eps, relu,
+                                          model.short_cut)
+            got = hiddens[i][rows].cpu().numpy()
+            assert np.array_equal(got, want.reshape(got.shape)), "layer %d differs from the oracle on the row subset" % (i + 1)
+
+        # ---- score head on 50 000 candidates, ranks over all of them
+        cand = torch.arange(2_000_000, 2_050_000, device=dev)
+        want = oracle.score_head_forward(hidden[cand].cpu().numpy(), q_np, first.weight.cpu().numpy(), first.bias.cpu().numpy(),
+                                         second.weight.cpu().numpy(), second.bias.cpu().numpy())
+        assert np.array_equal(scores[:, cand].cpu().numpy(), want), "score head differs from the oracle on the candidate subset"
+        ranks = task.rank_batch(batch, pred)
+        h, t, r = batch.t()
+        for side, (anc, tgt) in enumerate(((h, t), (t, h))):
+            row = pred[0, side]
+            el = task.graph.edge_list
+            known = el[(el[:, side] == anc[0]) & (el[:, 2] == r[0]), 1 - side]
+            mask = torch.ones(N, dtype=torch.bool, device=dev)
+            mask[known] = False
+            assert int(ranks[0, side]) == int(((row[tgt[0]] <= row) & mask).sum()) + 1, side
+
+        # ---- one layer's WHOLE output against the ATen definition (layer 2: dense input, dense output)
+        i = 1
+        w, b, g, beta, eps, relu = stack[i]["combine"]
+        x, table = hiddens[0].flatten(1), tables[i]
+        E = csr.n_edges
+        upd = torch.zeros(N, n_query * 64, device=dev)
+        scale = torch.zeros(N, n_query * 64, device=dev)
+        for e0 in range(0, E, 20_000_000):
+            sl = slice(e0, min(e0 + 20_000_000, E))
+            message = table[csr.rel_id[sl]] * x[csr.src[sl]]                    # layer.py:249-255 (distmult), unit weights
+            upd.index_add_(0, csr.dst[sl], message)                             # layer.py:275-276
+            scale.index_add_(0, csr.dst[sl], message.abs())
+            del message
+        upd = upd.view(N, n_query, 64)
+        upd[anchor, torch.arange(n_query, device=dev)] += query                 # + boundary (layer.py:358)
+        got_upd = ops.rspmm_forward(csr, table, x, "add", "mul", boundary=boundary).view(N, n_query, 64)
+        assert ((got_upd - upd).abs() <= 1e-5 * scale.view(N, n_query, 64) + 1e-6).all(), "rspmm differs from the ATen definition"
+        del scale, got_upd
+        want = torch.nn.functional.linear(torch.cat([hiddens[0], upd], dim=-1), w, b)          # layer.py:386-392
+        del upd
+        want = torch.relu(torch.nn.functional.layer_norm(want, (64,), g, beta, eps)) + hiddens[0]   # + shortcut (model.py:126-127)
+        err = (hiddens[1] - want).abs()
+        # measured on an MI355X: max 1.4e-6, mean 6.1e-8 (LayerNorm divides by the row's standard deviation: the errors of the
+        # 128-term dot products are amplified by 1 / std)
+        assert float(err.max()) <= 1e-5 and float(err.mean()) <= 5e-7, (float(err.max()), float(err.mean()))

@@ -18,24 +18,13 @@ import torch
 
 
 def build_stress_task(dev, n_node, n_triple, n_rel, seed=1024, log=None):
-    """The shipped architecture (seeded random init) over a uniform KG built on the device: SURVEY.md 8d's S-stress."""
-    from ultra_torchdrug_amd.graph import Graph
-    from ultra_torchdrug_amd.task import build_ultra
-    gen = torch.Generator(device=dev).manual_seed(seed)
-    h = torch.randint(0, n_node, (n_triple,), device=dev, generator=gen)
-    t = torch.randint(0, n_node, (n_triple,), device=dev, generator=gen)
-    r = torch.randint(0, n_rel, (n_triple,), device=dev, generator=gen)
-    triples = torch.stack([h, t, r], dim=1)
-    del h, t, r
-    torch.manual_seed(seed)
-    task = build_ultra(n_rel).to(dev).eval()
+    """ultra_torchdrug_amd.data.stress_task, timed."""
+    from ultra_torchdrug_amd.data import stress_task
     t0 = time.perf_counter()
-    graph = Graph.__new__(Graph)
-    Graph.__init__(graph, triples, None, n_node, n_rel)
-    task.preprocess(graph)
+    task, gen = stress_task(dev, n_node, n_triple, n_rel, seed)
     torch.cuda.synchronize()
     if log is not None:
-        log["relation_graph_build_s"] = time.perf_counter() - t0
+        log["task_build_s"] = time.perf_counter() - t0
         log["relation_graph_edges"] = int(task.rel_graphs[0].num_edge)
     return task, gen
 

@@ -428,7 +428,7 @@ int ultra_relation_graph_marks(const int32_t *head_ptr, const int32_t *head_rel,
                                int64_t n_node, int64_t n_rel, uint8_t *marks, void *stream) {
     if (n_node < 0 || n_rel <= 0 || n_rel > (1LL << 15) || n_node > 0x7fffffffLL) return ULTRA_ERR_BAD_SHAPE;
     if (marks == nullptr || (reinterpret_cast<uintptr_t>(marks) & 3u)) return ULTRA_ERR_NULL_POINTER;
-    if (n_node > 0 && (head_ptr == nullptr || tail_ptr == nullptr || head_rel == nullptr || tail_rel == nullptr)) return ULTRA_ERR_NULL_POINTER;
+    if (n_node > 0 && (head_ptr == nullptr || tail_ptr == nullptr)) return ULTRA_ERR_NULL_POINTER;     // (empty lists: the rel arrays may be NULL)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long n_words = (4 * n_rel * n_rel + 3) / 4;
     hipLaunchKernelGGL(marks_zero_kernel, dim3(grid_for(n_words)), dim3(kThreads), 0, s, reinterpret_cast<uint32_t *>(marks), n_words);

@@ -69,6 +69,24 @@ def synthetic_kg(name_or_shape="S-fb15k237", seed=DEFAULT_SEED, device="cpu", al
     return Graph(torch.from_numpy(triples).to(device), num_node=n_node, num_relation=n_rel)
 
 
+def stress_task(device, n_node=None, n_triple=None, n_rel=None, seed=DEFAULT_SEED):
+    """BASELINE config 5 as a TASK: the shipped 6 x 64d architecture (seeded random init) over S-stress built ON THE DEVICE --
+    uniform heads / tails / relations (duplicates, about 1 in 10^4, are merged by the plans) -- with every triple
+    a fact.  10 M nodes / 50 M triples / 500 relations by default: 100 M edges and 1 000 relations as rspmm sees them.
+    Returns ``(task in eval mode, generator)``; the generator continues the seeded stream (test batches)."""
+    from .task import build_ultra
+    d_node, d_triple, d_rel = SHAPES["S-stress"]
+    n_node, n_triple, n_rel = int(n_node or d_node), int(n_triple or d_triple), int(n_rel or d_rel)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    cols = [torch.randint(0, n, (n_triple,), device=device, generator=gen) for n in (n_node, n_node, n_rel)]
+    triples = torch.stack(cols, dim=1)
+    del cols
+    torch.manual_seed(seed)
+    task = build_ultra(n_rel).to(device).eval()
+    task.preprocess(Graph(triples, None, n_node, n_rel))
+    return task, gen
+
+
 def load_triples(path, entity_vocab=None, relation_vocab=None):
     """Read ``h<TAB>r<TAB>t`` lines (the layout of ``ultra/dataset.py:69-96``) into ``(h, t, r)`` ids."""
     entity_vocab = {} if entity_vocab is None else entity_vocab
