@@ -630,6 +630,69 @@ def test_sparse_first_layer_in_training_gives_the_gradients_of_the_dense_layer()
         UF.SPARSE_FIRST_LAYER_MIN_ROWS, UF.SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION = old_rows, old_fraction
 
 
+def test_sparse_first_layer_backward_survives_a_switch_to_the_full_d_relation_kernels():
+    """the sparse first layer's backward writes `d_update` at the listed rows only; every d_relation kernel but the
+    boundary one multiplies ALL of its rows (by the zero input row: 0 * NaN of uninitialised memory = NaN).  The forward now takes
+    the sparse form only where the backward will use the boundary kernel, and a backward that finds itself on another kernel (the
+    switch flipped in between, knob bits) zero-fills first.  Allocator blocks are poisoned with NaN before each step."""
+    from ultra_torchdrug_amd import functional as UF
+    dev = torch.device("cuda:0")
+    lib = UF._lib.load()
+    old_rows, old_fraction = UF.SPARSE_FIRST_LAYER_MIN_ROWS, UF.SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION
+    UF.SPARSE_FIRST_LAYER_MIN_ROWS, UF.SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION = 0, 1.0
+    try:
+        task, triples = _build((5000, 20000, 7))
+        task.num_negative = 32
+        task.to(dev).train()
+        batch = torch.from_numpy(triples[:16]).to(dev)
+
+        def poison():
+            junk = [torch.full((n,), float("nan"), device=dev) for n in (1 << 24, 1 << 22, 1 << 20, 5000 * 16 * 64, 5000 * 16 * 64)]
+            del junk
+
+        def step(flip=None):
+            task.zero_grad(set_to_none=True)
+            torch.manual_seed(3)
+            poison()
+            loss, _ = task(batch)
+            if flip is not None:
+                flip(True)
+            try:
+                poison()
+                loss.backward()
+            finally:
+                if flip is not None:
+                    flip(False)
+            return {k: p.grad.detach().clone() for k, p in task.named_parameters() if p.grad is not None}
+
+        want = step()
+
+        def flip_switch(on):
+            UF.BOUNDARY_DRELATION = not on
+
+        def flip_knob(on):
+            lib.ultra_rspmm_force_general_path(1 if on else 0)
+
+        for flip in (flip_switch, flip_knob):
+            got = step(flip)
+            assert got.keys() == want.keys()
+            for k in want:
+                assert bool(torch.isfinite(got[k]).all()), k
+                scale = want[k].abs().max().item()
+                assert (got[k] - want[k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
+        # with the switch off from the start the forward does not take the sparse form at all
+        UF.BOUNDARY_DRELATION = False
+        try:
+            got = step()
+        finally:
+            UF.BOUNDARY_DRELATION = True
+        for k in want:
+            assert bool(torch.isfinite(got[k]).all()) and (got[k] - want[k]).abs().max().item() <= 2e-5 * want[k].abs().max().item() + 1e-9, k
+    finally:
+        UF.SPARSE_FIRST_LAYER_MIN_ROWS, UF.SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION = old_rows, old_fraction
+        lib.ultra_rspmm_force_general_path(0)
+
+
 def test_score_head_on_candidate_rows_matches_the_reference_chain():
     """ultra_score_rows_* (gather of the candidate rows, concatenation with the query, the 128 -> 128 -> 1 mlp, and the whole
     backward, as one autograd node) against index + cat + nn.Linear chain in fp64 (ultra/model.py:177-183,193): scores and

@@ -1338,7 +1338,12 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
     if (ev_start != nullptr) HIP_TRY(stamp(ev_start));
     // dense relation graphs: the sum as a product with the plan's 0/1 matrix on the exact-f32 matrix cores -- the reference
     // order for every row, no pieces, no fix-up pass (relgraph_dense.hip)
-    if (seg->dense != nullptr && !g_no_dense && !g_force_general && !g_no_quad && !g_no_x_lds) {
+    // (only on the architecture the instruction's summation order was probed on -- tools/ubench/mfma_order.hip, MI355X: a build
+    // with ARCH=gfx942 walks the edge list -- and for finite operands only: fmaf(0, y, acc) == acc needs a finite y, so ONE
+    // non-finite activation turns every row of a dense launch into NaN where the edge walk and the reference touch that node's
+    // neighbours only; the eager callers test their relation tables as the frontier path does)
+    if (seg->dense != nullptr && !g_no_dense && !g_force_general && !g_no_quad && !g_no_x_lds &&
+        std::strncmp(di->arch, "gfx950", 6) == 0) {
         ultra_detail::DenseCall call{seg, KIND, sum_op, mul_op, p.relation, p.input, p.grad, p.add_rows, p.bnode, p.bvec, p.bdim,
                                      p.out, workspace, workspace_bytes, gather_rows, gather2_rows, n_rel, F};
         if (ultra_detail::dense_applies(call)) {

@@ -219,6 +219,15 @@ SPARSE_FIRST_LAYER = __import__("os").environ.get("ULTRA_SPARSE_FIRST_LAYER", "1
 SPARSE_FIRST_LAYER_MIN_ROWS = 1 << 17
 
 
+# The row list (and, in training, the compacted backward workspace: 5 x 64 floats per slot) is sized for the WORST head:
+# n_query * (max_runs + 1) slots.  The density gates look at the degree-weighted mean; one hub that reaches most of the nodes in an
+# otherwise sparse graph would pass them and allocate several (N, B, 64)-sized scratch tensors per step: the sparse
+# forms are taken only where the longest list is at most this fraction of the nodes (ULTRA_SPARSE_FIRST_LAYER_MAX_LIST).
+SPARSE_FIRST_LAYER_MAX_LIST = float(__import__("os").environ.get("ULTRA_SPARSE_FIRST_LAYER_MAX_LIST", "1.0"))
+# ... and, in training, where the backward's compacted workspace (5 rows of 64 floats per slot) stays within this many bytes
+SPARSE_FIRST_LAYER_TRAIN_MAX_BYTES = int(__import__("os").environ.get("ULTRA_SPARSE_FIRST_LAYER_TRAIN_MAX_BYTES", str(2 << 30)))
+
+
 def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True,
                         shortcut=False):
     """The whole FIRST Bellman-Ford layer in inference -- ``rspmm_frontier`` followed by ``combine_forward(None, update, ...,
@@ -233,7 +242,8 @@ def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, l
     n_query = b_node.shape[0]
     lib = _lib.load()
     if (n_dst != n_src or n_dst * n_query < SPARSE_FIRST_LAYER_MIN_ROWS
-            or not lib.ultra_first_layer_sparse_supported(n_dst, n_rel, n_query)):
+            or not lib.ultra_first_layer_sparse_supported(n_dst, n_rel, n_query)
+            or csr.frontier_runs[1] + 1 > SPARSE_FIRST_LAYER_MAX_LIST * n_dst):
         return None
     F = n_query * 64
     b_value = b_value.contiguous()
@@ -285,7 +295,9 @@ def first_layer_train_forward(csr, relation, boundary, weight, bias, ln_weight=N
     lib = _lib.load()
     if (n_dst != n_src or n_dst * n_query < SPARSE_FIRST_LAYER_MIN_ROWS or n_dst * n_query > (1 << 24) - 64
             or not lib.ultra_first_layer_sparse_supported(n_dst, n_rel, n_query)
-            or csr.frontier_fraction > SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION):
+            or csr.frontier_fraction > SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION
+            or csr.frontier_runs[1] + 1 > SPARSE_FIRST_LAYER_MAX_LIST * n_dst
+            or n_query * (csr.frontier_runs[1] + 1) * 5 * 256 > SPARSE_FIRST_LAYER_TRAIN_MAX_BYTES):
         return None
     F = n_query * 64
     b_value = b_value.contiguous()
@@ -1221,7 +1233,10 @@ class _SumLayerFunction(torch.autograd.Function):
         if first_layer and (torch.cuda.is_current_stream_capturing() or bool(torch.isfinite(relation).all())):
             # first layer: only the boundary nodes' out-edges carry a message (same bits as the full kernel, finite tables:
             # see rspmm_frontier) -- as in inference; and the epilogue runs on the rows they reach only (first_layer_train_forward)
-            if mul == "mul" and grad_tiles is None and not KEEP_PRE_NORM:
+            # (only where the backward takes d_relation from the boundary nodes' out-edges: every other d_relation kernel multiplies
+            # ALL d_update rows, which the sparse backward writes at the listed rows only -- ADVICE r5)
+            if (mul == "mul" and grad_tiles is None and not KEEP_PRE_NORM and BOUNDARY_DRELATION
+                    and not csr.kernel_order("add", "mul", flat.shape[1])[1]):
                 sparse = first_layer_train_forward(csr, relation.detach(), boundary, weight, bias, ln_weight, ln_bias, ln_eps, relu,
                                                    shortcut)
             update = rspmm_frontier(csr, relation.detach(), boundary) if sparse is None else sparse[0].flatten(1)
@@ -1263,12 +1278,19 @@ class _SumLayerFunction(torch.autograd.Function):
         n_waves = ctypes.c_int(0)
         _lib.check(lib.ultra_combine_backward_fused_waves(dev.index or 0, rows, ctypes.byref(n_waves)))
         ws = torch.empty(n_waves.value * (64 * 128 + 192), dtype=torch.float32, device=dev)
-        d_input, d_update = torch.empty_like(input_c), torch.empty_like(update_c)
+        first_rows = getattr(ctx, "first_rows", None)
+        # first layer: d_relation from the boundary nodes' out-edges (reads d_update at the rows those edges reach only)?
+        drel_boundary = bool(ctx.boundary_rows_only and needs[2] and needs[1] and BOUNDARY_DRELATION and ctx.mul == "mul"
+                             and not ctx.csr.kernel_order("add", "mul", update_c[0].numel())[1])
+        d_input = torch.empty_like(input_c)
+        # The sparse first-layer backward writes d_update at the LISTED rows only.  Any other consumer than the boundary kernels
+        # (a knob or switch flipped between forward and backward: the full / masked d_relation kernels multiply every d_update row
+        # by the zero input row, and 0 * NaN of uninitialised memory is NaN) gets zeros elsewhere.
+        d_update = torch.empty_like(update_c) if (first_rows is None or drel_boundary) else torch.zeros_like(update_c)
         d_weight = torch.empty(64, 128, dtype=torch.float32, device=dev)
         d_bias = torch.empty(64, dtype=torch.float32, device=dev)
         d_g = torch.empty(64, dtype=torch.float32, device=dev) if has_ln else None
         d_b = torch.empty(64, dtype=torch.float32, device=dev) if has_ln else None
-        first_rows = getattr(ctx, "first_rows", None)
         if first_rows is not None:
             # sparse first layer (csrc/first_layer_train.inc): the listed rows compacted and run through the one-pass backward, every
             # other row's share of d_bias / d_gamma / d_beta from the column sums of grad_out; d_update is written (and later read) at
@@ -1297,7 +1319,7 @@ class _SumLayerFunction(torch.autograd.Function):
         flat_du = d_update.flatten(1)
         if ctx.boundary_rows_only and needs[2]:
             # first layer: the input is zero outside row b_node[q] of block q -- d_relation needs that node's out-edges only
-            if needs[1] and BOUNDARY_DRELATION and ctx.mul == "mul" and not ctx.csr.kernel_order("add", "mul", flat_du.shape[1])[1]:
+            if drel_boundary:
                 d_relation = rspmm_drelation_boundary(ctx.csr, input_c.flatten(1), flat_du, ctx.b_node)
             else:
                 _, d_relation = rspmm_backward(ctx.csr, relation, input_c.flatten(1), None, flat_du, "add", ctx.mul,

@@ -312,19 +312,22 @@ class TransferNBFNet(nn.Module):
         every row of the corrupted side lists ALL entities in order (full-batch evaluation, task.py:249-259); the
         tail gather is then the identity and the score head runs as one fused kernel."""
         keep, removal = None, None
-        if self.check_indices and r_index is not None:
+        if self.check_indices:
             # BEFORE anything consumes the ids (edge removal, negative flip, the fused kernels index with them without a bounds
             # check of their own -- frontier: src_ptr[h]; candidate tiles: an LDS bitmap at (t, b); score rows: hidden[t, b]): an id
             # from another split's vocabulary fails in an ATen index kernel in the reference and must fail HERE, not corrupt
             # memory (ADVICE r3 / r4); one stacked host read; captured steps validate their batches once instead
-            # (engine.validate_triples).  Relation ids are checked against the graph's own vocabulary, before inverses double it.
-            n_node, n_rel = graph.num_node, max(graph.num_relation, 1)
-            bad = ((h_index < 0) | (h_index >= n_node) | (t_index < 0) | (t_index >= n_node)
-                   | (r_index < 0) | (r_index >= n_rel)).any()
-            if bool(bad):
+            # (engine.validate_triples).  Relation ids are checked against the graph's own vocabulary, before inverses double it;
+            # on the homogeneous path (no r_index) the entity ids are checked all the same (ADVICE r5).
+            n_node, n_rel = graph.num_node, max(graph.num_relation or 0, 1)
+            bad = (h_index < 0) | (h_index >= n_node) | (t_index < 0) | (t_index >= n_node)
+            if r_index is not None:
+                bad = bad | (r_index < 0) | (r_index >= n_rel)
+            if bool(bad.any()):
+                r_lo, r_hi = (int(r_index.min()), int(r_index.max())) if r_index is not None else (0, 0)
                 raise IndexError("entity ids must lie in [0, %d) and relation ids in [0, %d): got h in [%d, %d], t in [%d, %d], "
                                  "r in [%d, %d]" % (n_node, n_rel, int(h_index.min()), int(h_index.max()), int(t_index.min()),
-                                                    int(t_index.max()), int(r_index.min()), int(r_index.max())))
+                                                    int(t_index.max()), r_lo, r_hi))
         if all_loss is not None:
             # training: the batch's own positive edges must not carry messages (model.py:146-147).  The reference
             # builds (and torchdrug re-sorts) a new graph every step; here the cached plans of the full graph are
