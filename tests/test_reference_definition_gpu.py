@@ -213,6 +213,13 @@ def test_entity_stack_hip_path_equals_aten_definition_path(name, B):
     assert e_hip <= 2e-4 * scale
 
 
+# Floor of the stack test's gradient bar, in units of each gradient's scale.  The HIP path is deterministic; measured on an
+# MI355X (round 6): sum / distmult 9.7e-7, mean / distmult 8.8e-7, mean / transe 1.2e-6 -- and sum / transe 1.06e-3
+# (layers.1.linear.weight: one pre-activation within fp32 rounding of zero lands on the other side of the ReLU than in fp64).
+STACK_GRADIENT_FLOORS = {("sum", "transe"): 2e-3}
+STACK_GRADIENT_FLOOR = 5e-4
+
+
 @pytest.mark.parametrize("aggregate_func", ["sum", "mean", "max", "pna"])
 @pytest.mark.parametrize("message_func", ["distmult", "transe"])
 def test_every_aggregate_and_message_of_the_layers_matches_the_aten_definition(aggregate_func, message_func):
@@ -273,11 +280,15 @@ def test_every_aggregate_and_message_of_the_layers_matches_the_aten_definition(a
     # the fp64 truth moves by orders of magnitude on the same inputs -- layers.0.layer_norm.weight of transe / sum:
     # 1.1 in most runs, 0.0017 in some (scale 843), depending on which pre-activations near zero land on which side of
     # the ReLU -- while the HIP path gives the same bits every time (0.209 there; 0.53 on a scale of 893 for the first
-    # projection bias).  The floor of the bar is therefore 2e-3 of the gradient's scale, the size of such flips, not 1e-5.
+    # projection bias).  The floor of the bar is therefore the size of such flips (STACK_GRADIENT_FLOORS above), not 1e-5.
+    worst = (0.0, 0.0, "")
     for k in g_true:
         s = g_true[k].abs().max().item() + 1e-12
         e_hip, e_aten = err(results["hip"][1][k], g_true[k]), err(results["aten"][1][k], g_true[k])
-        assert e_hip <= 4 * e_aten + 2e-3 * s, "%s: HIP %.3g vs ATen-fp32 %.3g away from fp64 (scale %.3g)" % (k, e_hip, e_aten, s)
+        worst = max(worst, (e_hip / s, e_aten / s, k))
+        assert e_hip <= 4 * e_aten + STACK_GRADIENT_FLOORS.get((aggregate_func, message_func), STACK_GRADIENT_FLOOR) * s, "%s: HIP %.3g vs ATen-fp32 %.3g away from fp64 (scale %.3g)" % (k, e_hip, e_aten, s)
+    print("%s / %s stack vs fp64 definition: worst relative gradient error HIP %.2e (ATen-fp32 there %.2e) at %s"
+          % (aggregate_func, message_func, worst[0], worst[1], worst[2]))
 
 
 @pytest.mark.parametrize("n_query", [2, 16, 32])
@@ -418,7 +429,9 @@ def test_whole_finetune_step_at_wn18rr_batch_16_equals_the_aten_definition():
         s = g_true[k].abs().max().item() + 1e-12
         e_hip, e_aten = (g_hip[k] - g_true[k]).abs().max().item(), (g_aten[k] - g_true[k]).abs().max().item()
         worst[k] = (e_hip / s, e_aten / s)
-        assert e_hip <= 4 * e_aten + 2e-3 * s, "%s: HIP %.3g vs ATen-fp32 %.3g away from fp64 (scale %.3g)" % (k, e_hip, e_aten, s)
+        # floor: 5e-4 of the gradient's scale (round 6; was 2e-3).  The HIP step is deterministic and measures 3.1e-5 ... 1.0e-4
+        # here: a fused backward that got 5 x worse must fail, whatever the irreproducible fp32 ATen side happens to show
+        assert e_hip <= 4 * e_aten + 5e-4 * s, "%s: HIP %.3g vs ATen-fp32 %.3g away from fp64 (scale %.3g)" % (k, e_hip, e_aten, s)
     print("finetune step vs fp64 definition: worst relative gradient error HIP %.2e, ATen-fp32 %.2e"
           % (max(v[0] for v in worst.values()), max(v[1] for v in worst.values())))
 
@@ -483,6 +496,8 @@ def test_whole_pretraining_step_at_batch_64_equals_the_aten_definition(name):
         s = g_true[k].abs().max().item() + 1e-12
         e_hip, e_aten = (g_hip[k] - g_true[k]).abs().max().item(), (g_aten[k] - g_true[k]).abs().max().item()
         worst[k] = (e_hip / s, e_aten / s)
-        assert e_hip <= 4 * e_aten + 2e-3 * s, "%s: HIP %.3g vs ATen-fp32 %.3g away from fp64 (scale %.3g)" % (k, e_hip, e_aten, s)
+        # floor: 5e-4 of the gradient's scale (round 6; was 2e-3).  The HIP step is deterministic and measures 3.1e-5 ... 1.0e-4
+        # here: a fused backward that got 5 x worse must fail, whatever the irreproducible fp32 ATen side happens to show
+        assert e_hip <= 4 * e_aten + 5e-4 * s, "%s: HIP %.3g vs ATen-fp32 %.3g away from fp64 (scale %.3g)" % (k, e_hip, e_aten, s)
     print("%s pre-training step (B = 64) vs fp64 definition: worst relative gradient error HIP %.2e, ATen-fp32 %.2e"
           % (name, max(v[0] for v in worst.values()), max(v[1] for v in worst.values())))
