@@ -49,11 +49,19 @@ def main():
     reducer_g = engine.GradientReducer(twin, overlap=True)
     graphed = engine.GraphedMultiGraphTrainStep(twin, opt_g, B, reducer=reducer_g)
     after_init = reducer_g.total_launched
-    per_step, negatives, losses_g = [], [], []
+    per_step, negatives, losses_g, sums, said = [], [], [], [], []
     for batch in batches:
-        before = reducer_g.total_launched
+        before, sent_before = reducer_g.total_launched, reducer_g.collectives
         loss, _ = graphed(batch)
         per_step.append(reducer_g.total_launched - before)
+        # what crossed the phase boundaries of THIS step: the groups this rank sent, in order, and -- after the round -- the flat
+        # buffer every rank's optimizer read: averaged gradients, so bit-identical on all ranks whatever graph each rank was on
+        # (a phase of an FB15k237-shaped step is several times longer than a WN18RR-shaped one: if a group of one rank ever paired
+        # with another group of the other, sizes or contents would differ here)
+        torch.cuda.synchronize()
+        said.append(reducer_g.sent[-(reducer_g.collectives - sent_before):])
+        flat = reducer_g._flat_all
+        sums.append([float(flat.double().sum()), float(flat.double().abs().sum()), int(flat.view(torch.int32).long().sum())])
         negatives.append(graphed.steps[batch[1]].last_negatives.clone())
         losses_g.append(float(loss))
     torch.cuda.synchronize()
@@ -77,7 +85,14 @@ def main():
                           | int(getattr(props, "pci_device_id", dev.index or 0))], dtype=torch.int64, device=dev)
     idents = [torch.zeros_like(ident) for _ in range(world)]
     dist.all_gather(idents, ident)
-    print(json.dumps({"rank": rank, "backend": dist.get_backend(), "distinct_devices": len({int(t.item()) for t in idents}),
+    mine = torch.tensor(sums, dtype=torch.float64, device=dev)
+    theirs = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(theirs, mine)
+    print(json.dumps({"rank": rank, "groups_sent_per_step": said, "groups": [list(g) for g in reducer_g.groups],
+                      "reduced_buffers_equal_on_all_ranks_per_step": [bool(all(torch.equal(theirs[0][i], t[i]) for t in theirs[1:]))
+                                                                      for i in range(len(sums))],
+                      "reduced_buffer_nonzero_per_step": [s[1] > 0 for s in sums],
+                      "backend": dist.get_backend(), "distinct_devices": len({int(t.item()) for t in idents}),
                       "modes": graphed.modes, "buckets": len(reducer_g.buckets), "warm_launches": after_init, "per_step": per_step,
                       "captured": sorted(graphed.steps), "graphed_equals_eager": equal, "losses_equal": losses_g == losses_e,
                       "ranks_hold_equal_parameters": bool(all(torch.equal(both[0], b) for b in both[1:])),

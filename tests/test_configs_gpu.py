@@ -385,3 +385,10 @@ def test_multi_graph_graphed_steps_on_two_ranks_that_draw_different_graphs():
         # what ran the collectives: on a node with two GPUs this IS RCCL on two different devices (the first such run must say so)
         assert rep["backend"] == backend and rep["distinct_devices"] == (2 if backend == "nccl" else 1), rep
         assert len(set(rep["modes"].values())) == 1 and rep["modes"] == reports[0]["modes"], rep
+        # the phase boundaries: on every step every rank sent the same groups in the same order (one all-reduce per group, whichever
+        # graph -- i.e. however long a phase -- the rank was on), and the reduced buffer the optimizers read was the same on both
+        n_groups = len(rep["groups"])
+        for said in rep["groups_sent_per_step"]:
+            assert [g for g, _ in said] == list(range(n_groups)), rep["groups_sent_per_step"]
+        assert rep["groups_sent_per_step"] == reports[0]["groups_sent_per_step"], (rep["groups_sent_per_step"], reports[0]["groups_sent_per_step"])
+        assert all(rep["reduced_buffers_equal_on_all_ranks_per_step"]) and all(rep["reduced_buffer_nonzero_per_step"]), rep

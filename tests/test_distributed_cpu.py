@@ -146,6 +146,18 @@ def _worker(rank, world, port, out_dir):
             engine.train_step(multi, opt_m, (pools[gid][50 * s + 8 * rank: 50 * s + 8 * rank + 8], gid), reducer=reducer)
             assert reducer.total_launched - before == len(reducer.buckets) and reducer.rounds == s + 1
             assert reducer.collectives == 3 * (s + 2)           # warm() + one all-reduce per GROUP and step
+            # what this rank SAID in this step: groups 0, 1, 2 in order, each its whole slice of the flat buffer -- the same
+            # sequence on the rank that is on the other graph (compared below), and the same reduced buffer on both
+            assert [g for g, _ in reducer.sent[-3:]] == [0, 1, 2]
+            assert [n for _, n in reducer.sent[-3:]] == [sum(reducer.buckets[b]["numel"] for b in grp) for grp in reducer.groups]
+            said = torch.tensor(reducer.sent[-3:], dtype=torch.int64)
+            both_said = [torch.zeros_like(said) for _ in range(world)]
+            dist.all_gather(both_said, said)
+            assert torch.equal(both_said[0], both_said[1])
+            flat = reducer._flat_all.clone()
+            both_flat = [torch.zeros_like(flat) for _ in range(world)]
+            dist.all_gather(both_flat, flat)
+            assert torch.equal(both_flat[0], both_flat[1]) and float(flat.abs().sum()) > 0
     multi._static_negative = None
     reducer.remove_hooks()
     hop_params = torch.cat([p.detach().reshape(-1) for p in multi.parameters()])

@@ -790,6 +790,7 @@ class GradientReducer:
         self.launched_from_hooks = 0            # buckets packed (and their groups sent) from hooks, i.e. during backward, last step
         self.total_launched = 0                 # buckets whose reduction was issued since construction (gradient rounds + warm())
         self.collectives = 0                    # all-reduce calls issued since construction
+        self.sent = []                          # (group, elements) of the last 64 collectives, in issue order: what a rank SAID
         self.rounds = 0                         # completed rounds that carried gradients
         self._reset()
         if overlap:
@@ -884,6 +885,7 @@ class GradientReducer:
         else:
             self._work[g] = dist.all_reduce(flat, op=op, async_op=True)
         self.collectives += 1
+        self.sent = (self.sent + [(g, int(flat.numel()))])[-64:]
 
     def warm(self):
         """One explicit all-reduce per group, in order, on the side stream: initialises RCCL's channels and allocates the
