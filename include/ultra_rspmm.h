@@ -676,6 +676,26 @@ int ultra_dense_layer_forward_f32(const ultra_segments *fwd, const float *relati
                                   int shortcut, float *out, void *stream);
 
 /*
+ * One whole layer of the ENTITY Bellman-Ford in inference as one launch (ABI 8; csrc/layer_fused.hip), for plans that run one row
+ * per lane group (big graphs: row_ptr present, no split rows -- BASELINE config 5, S-stress):
+ *     out = [input +] relu(LayerNorm(Linear_{128->64}(cat[input, rspmm_{add,mul}(input) + boundary])))
+ * = GeneralizedRelationalConv*.message_and_aggregate + combine (/root/reference/ultra/layer.py:298-392: rspmm :357, + boundary :358,
+ * combine :386-392) + the shortcut of ultra/model.py:126-127 -- ultra_rspmm_forward_boundary_f32 followed by
+ * ultra_combine_forward_f32, bit for bit, with the epilogue INSIDE the rspmm's row loop: a wave stages the four epilogue rows it
+ * finishes per iteration (and their own input segments) in LDS and runs the 128 -> 64 product on the exact-f32 matrix cores every
+ * fourth iteration (v_mfma_f32_16x16x4_f32, K = (in[s], up[s], in[s+1], up[s+1]): the chain of ultra_combine_forward_f32), so the
+ * (N, B, 64) tensor `update` is never written or read: 2 of a layer's 5 row-sized streams.
+ *   fwd: the forward plan (row_ptr != NULL, n_pieces == 0: ultra_layer_forward_supported);  input [n_rows, n_query, 64] (the
+ *   gathered matrix AND the epilogue's `input`);  relation [n_rel, n_query * 64];  boundary as in ultra_rspmm_forward_boundary_f32
+ *   with block = 64 (both NULL: no boundary term);  weight [64, 128];  out [n_rows, n_query, 64], NOT aliasing input.
+ */
+int ultra_layer_forward_supported(const ultra_segments *fwd, int64_t n_query, int64_t n_rel);
+int ultra_layer_forward_f32(const ultra_segments *fwd, const float *relation, const float *input, const int32_t *boundary_node,
+                            const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                            const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut, float *out,
+                            int64_t n_rel, void *stream);
+
+/*
  * The graph of relations, natively (ABI 8): construct_relation_graph, /root/reference/ultra/rel_model.py:91-143.  The reference
  * multiplies the (2R x N) and (N x 2R) incidence matrices of the graph with inverse edges four ways -- Eh^T Eh, Et^T Et, Eh^T Et,
  * Et^T Eh -- and keeps the INDICES of each product (`block.coalesce().indices()`, :131-139): relations r1, r2 get an edge of

@@ -1,0 +1,94 @@
+"""One entity layer of a Bellman-Ford in inference as ONE launch (csrc/layer_fused.hip, `functional.layer_forward`): the rspmm of
+the row-per-group kernel with the 128 -> 64 epilogue inside its row loop.  SURVEY.md 8f-1 ("fusing into the rspmm row tile removes
+one full read + write of (N, F) per layer"; /root/reference/ultra/layer.py:357-358,386-392, ultra/model.py:126-127).
+
+The bar is EQUALITY with the two launches it replaces (`rspmm_forward(..., boundary=)` + `combine_forward`), which the other tests
+hold to the oracle: every lane-group width (16 / 32 / 64 lanes per row), relation rows from LDS / partly from LDS / from L2, rows
+of more than one 16-edge window, empty rows, a row count that leaves the last batch of four iterations ragged, per-edge weights,
+with and without LayerNorm / relu / shortcut / boundary.
+"""
+import numpy as np
+import pytest
+import torch
+
+from graphs import random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _layer_params(gen, dev, layer_norm=True):
+    w = torch.randn(64, 128, device=dev, generator=gen) * 0.1
+    b = torch.randn(64, device=dev, generator=gen) * 0.1
+    g = (1 + 0.1 * torch.randn(64, device=dev, generator=gen)) if layer_norm else None
+    beta = (0.1 * torch.randn(64, device=dev, generator=gen)) if layer_norm else None
+    return w, b, g, beta
+
+
+CASES = {
+    # name: (n_node, n_edge, n_rel, n_query, knob, weights)
+    "g16_rel_lds": (3001, 24000, 30, 1, 0, False),
+    "g16_three_queries": (2500, 20000, 30, 3, 0, False),
+    "g32_rel_part": (3003, 30000, 250, 2, 16, False),
+    "g64_rel_l2": (2002, 16000, 1000, 4, 16, False),
+    "g64_two_tiles": (1501, 12000, 40, 8, 16, False),
+    "g32_weights": (2000, 18000, 60, 2, 16, True),
+    "g16_rel_l2_weights": (1800, 15000, 900, 1, 0, True),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_fused_layer_equals_rspmm_plus_epilogue(case):
+    from ultra_torchdrug_amd import RelCSR, _lib, functional as UF
+    dev = _dev()
+    n, e, r, n_query, knob, weights = CASES[case]
+    g = random_graph(seed=len(case), n_node=n, n_edge=e, n_rel=r, weights=weights)
+    g["dst"][:40] = 7                                     # a row of three windows
+    g["dst"][40:60] = n - 1                               # the last row: two windows
+    keep = g["dst"] != 11                                 # an empty row
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    csr = RelCSR(t(g["dst"][keep]), t(g["src"][keep]), t(g["rel"][keep]), t(g["w"][keep]) if weights else None, n, n, r,
+                 wide_ids=True, piece_len=512)
+    assert csr.fwd.row_ptr is not None and csr.fwd.n_pieces == 0
+    gen = torch.Generator(device=dev).manual_seed(5)
+    F = 64 * n_query
+    x = torch.randn(n, n_query, 64, device=dev, generator=gen)
+    relation = torch.randn(r, F, device=dev, generator=gen)
+    b_node = torch.randint(0, n, (n_query,), device=dev, generator=gen).to(torch.int32)
+    b_node[0] = 7
+    b_value = torch.randn(n_query, 64, device=dev, generator=gen)
+    lib = _lib.load()
+    lib.ultra_rspmm_force_general_path(knob)
+    try:
+        for layer_norm, relu, shortcut, with_boundary in ((True, True, True, True), (False, True, False, True),
+                                                          (True, False, True, False), (True, True, False, True)):
+            w, b, gamma, beta = _layer_params(gen, dev, layer_norm)
+            boundary = (b_node, b_value) if with_boundary else None
+            update = UF.rspmm_forward(csr, relation, x.flatten(1), "add", "mul", boundary=boundary).view(n, n_query, 64)
+            want = UF.combine_forward(x, update, w, b, gamma, beta, 1e-5, relu, shortcut)
+            got = UF.layer_forward(csr, relation, x, boundary, w, b, gamma, beta, 1e-5, relu, shortcut)
+            assert got is not None, "the fused entry declined a row-per-group plan"
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (case, layer_norm, relu, shortcut, with_boundary,
+                                            float((got - want).abs().max()), int((got != want).any(-1).sum()))
+            again = UF.layer_forward(csr, relation, x, boundary, w, b, gamma, beta, 1e-5, relu, shortcut)
+            assert torch.equal(got, again)
+    finally:
+        lib.ultra_rspmm_force_general_path(0)
+
+
+def test_fused_layer_declines_what_it_does_not_cover():
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    dev = _dev()
+    g = random_graph(seed=2, n_node=500, n_edge=4000, n_rel=9)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    csr = RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), None, 500, 500, 9)          # a packed plan: the chunked kernels
+    gen = torch.Generator(device=dev).manual_seed(1)
+    w, b, gamma, beta = _layer_params(gen, dev)
+    x = torch.randn(500, 2, 64, device=dev, generator=gen)
+    relation = torch.randn(9, 128, device=dev, generator=gen)
+    assert UF.layer_forward(csr, relation, x, None, w, b, gamma, beta) is None

@@ -122,6 +122,8 @@ EXPORTS = (
     "ultra_column_sum_f32",
     "ultra_dense_layer_supported",
     "ultra_dense_layer_forward_f32",
+    "ultra_layer_forward_supported",
+    "ultra_layer_forward_f32",
 )
 
 _lib = None
@@ -152,6 +154,10 @@ def load():
     seg = ctypes.POINTER(UltraSegments)
     lib.ultra_rspmm_abi_version.restype = i32
     lib.ultra_rspmm_abi_version.argtypes = []
+    lib.ultra_layer_forward_supported.restype = i32
+    lib.ultra_layer_forward_supported.argtypes = [seg, i64, i64]
+    lib.ultra_layer_forward_f32.restype = i32
+    lib.ultra_layer_forward_f32.argtypes = [seg, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, vp]
     lib.ultra_relation_graph_marks.restype = i32
     lib.ultra_relation_graph_marks.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp]
     lib.ultra_segments_bytes.restype = sz

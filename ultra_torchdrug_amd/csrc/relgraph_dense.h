@@ -29,6 +29,12 @@ struct DenseCall {
     int64_t gather_rows, gather2_rows, n_rel, F;
 };
 
+// compute units the persistent grids of this process are sized for on the current device (the device's count minus
+// ultra_rspmm_reserve_cus); implemented in rspmm_kernels.hip, used by the other translation units' launches
+int persistent_cus(int *n_cu);
+// knob bit 4 of ultra_rspmm_force_general_path: wide lane groups (32 / 64 lanes per row) on inputs small enough to be cache-resident
+bool wide_groups_forced();
+
 bool dense_applies(const DenseCall &call);
 int dense_launch(const DenseCall &call, hipStream_t stream);
 

@@ -1537,6 +1537,19 @@ int run_plan(const ultra_segments *seg, KParams p, int64_t gather_rows, int64_t 
 
 }  // namespace
 
+namespace ultra_detail {
+int persistent_cus(int *n_cu) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo *di = nullptr;
+    const int rc = device_info(dev, &di);
+    if (rc) return rc;
+    *n_cu = di->n_cu;
+    return ULTRA_OK;
+}
+bool wide_groups_forced() { return g_wide_groups; }
+}  // namespace ultra_detail
+
 extern "C" {
 
 int ultra_rspmm_abi_version(void) { return ULTRA_RSPMM_ABI_VERSION; }

@@ -323,6 +323,45 @@ def first_layer_train_forward(csr, relation, boundary, weight, bias, ln_weight=N
     return update, out, row_list, list_offset[n_query:]
 
 
+# Entity layers in inference as ONE launch (rspmm + epilogue, csrc/layer_fused.hip) on plans that run one row per lane group
+# (big graphs: row pointers, no split rows).  ULTRA_FUSED_LAYER=0: the two launches (same bits).
+FUSED_LAYER = __import__("os").environ.get("ULTRA_FUSED_LAYER", "1") != "0"
+
+
+def layer_forward(csr, relation, input, boundary, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True,
+                  shortcut=False):
+    """``[input +] relu(LN(Linear(cat[input, rspmm(csr, relation, input, "add", "mul") + boundary])))`` -- one entity layer of a
+    Bellman-Ford in inference (/root/reference/ultra/layer.py:298-392, ultra/model.py:126-127) -- in ONE launch where the forward
+    plan runs one row per lane group: ``rspmm_forward(..., boundary=)`` + ``combine_forward`` bit for bit, without the ``update``
+    tensor ever reaching memory.  ``input``: ``(N, Q, 64)``; ``boundary = (node int32 (Q,), value fp32 (Q, 64))`` or ``None``.
+    Returns ``(N, Q, 64)`` (a new tensor), or ``None`` where the fused entry does not apply (the caller runs the two calls)."""
+    if not FUSED_LAYER or input.dim() != 3 or input.shape[-1] != 64:
+        return None
+    n_dst, n_src, n_rel = csr.shape
+    n_query = input.shape[1]
+    lib = _lib.load()
+    plan = csr.fwd
+    if n_dst != n_src or input.shape[0] != n_src or not lib.ultra_layer_forward_supported(plan.pointer, n_query, n_rel):
+        return None
+    F = n_query * 64
+    b_node, b_value = (None, None) if boundary is None else boundary
+    tensors = [relation, input, weight, bias] + ([ln_weight, ln_bias] if ln_weight is not None else []) + ([b_value] if b_value is not None else [])
+    if (tuple(relation.shape) != (n_rel, F) or tuple(weight.shape) != (64, 128)
+            or any(t.dtype != torch.float32 or not t.is_cuda or t.device != input.device for t in tensors)
+            or (b_node is not None and (b_node.dtype != torch.int32 or tuple(b_node.shape) != (n_query,) or tuple(b_value.shape) != (n_query, 64)))):
+        return None
+    relation, input = relation.contiguous(), input.contiguous()
+    out = torch.empty_like(input)
+    with torch.cuda.device(input.device):
+        _lib.check(lib.ultra_layer_forward_f32(
+            plan.pointer, relation.data_ptr(), input.data_ptr(), b_node.contiguous().data_ptr() if b_node is not None else None,
+            b_value.contiguous().data_ptr() if b_value is not None else None, n_query, weight.contiguous().data_ptr(),
+            bias.contiguous().data_ptr(), ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
+            ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
+            out.data_ptr(), n_rel, _stream()))
+    return out
+
+
 # Relation-graph layers in inference as ONE launch where the plan carries its dense form (ultra_dense_layer_forward_f32).
 # ULTRA_DENSE_LAYER=0: the dense rspmm and the epilogue as two launches (same bits).
 DENSE_LAYER = __import__("os").environ.get("ULTRA_DENSE_LAYER", "1") != "0"

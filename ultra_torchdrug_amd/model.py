@@ -283,6 +283,11 @@ class TransferNBFNet(nn.Module):
                     hidden = ops.combine_forward(None, update, w, b, g, beta, eps, relu, self.short_cut, reuse_update=True,
                                                  input_boundary=boundary)
             else:
+                # big graphs (one row per lane group): rspmm and epilogue in one launch, `update` never in memory; same bits
+                fused = ops.layer_forward(csr, tables[i], hidden, boundary, w, b, g, beta, eps, relu, self.short_cut)
+                if fused is not None:
+                    hidden = fused
+                    continue
                 update = ops.rspmm_forward(csr, tables[i], hidden.flatten(1), "add", "mul", boundary=boundary)
                 hidden = ops.combine_forward(hidden, update.view(n_node, n_query, 64), w, b, g, beta, eps, relu, self.short_cut,
                                              reuse_update=True)
