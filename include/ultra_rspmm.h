@@ -696,6 +696,24 @@ int ultra_layer_forward_f32(const ultra_segments *fwd, const float *relation, co
                             int64_t n_rel, void *stream);
 
 /*
+ * The LAST entity layer of full-batch evaluation with the score head inside the same launch (ABI 8; csrc/layer_fused.hip):
+ *     score[q, n] = w2 . relu(W1 . cat[hidden_L[n, q], query[q]] + b1) + b2,   hidden_L = ultra_layer_forward_f32(...)
+ * = ultra_layer_forward_f32 followed by ultra_score_forward_f32 (/root/reference/ultra/model.py:134-138,177-193 after the last
+ * layer of :120-130), bit for bit: the 16 finished rows of a flush go through the head's 64 -> 128 product on the matrix cores
+ * (the chain  c[q], hid[0], hid[32], hid[1], hid[33], ...  of score_kernel), relu and the w2 dot (one lane per row, o ascending)
+ * before anything leaves: the last layer's (N, Q, 64) output is neither written nor read again, only (Q, N) scores are stored.
+ *   query [n_query, 64];  w1 [128, 128], b1 [128], w2 [128], b2 [1];  qbias: fp32 [n_query, 128]
+ *   scratch (the queries' share of the head's first layer, written by a small launch in front);  score [n_query, n_rows].
+ *   n_query <= 32, n_query * n_rows * 4 B < 4 GiB (ultra_layer_score_supported).
+ */
+int ultra_layer_score_supported(const ultra_segments *fwd, int64_t n_query, int64_t n_rel);
+int ultra_layer_score_forward_f32(const ultra_segments *fwd, const float *relation, const float *input, const int32_t *boundary_node,
+                                  const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                                  const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                                  const float *query, const float *w1, const float *b1, const float *w2, const float *b2,
+                                  float *qbias, float *score, int64_t n_rel, void *stream);
+
+/*
  * The graph of relations, natively (ABI 8): construct_relation_graph, /root/reference/ultra/rel_model.py:91-143.  The reference
  * multiplies the (2R x N) and (N x 2R) incidence matrices of the graph with inverse edges four ways -- Eh^T Eh, Et^T Et, Eh^T Et,
  * Et^T Eh -- and keeps the INDICES of each product (`block.coalesce().indices()`, :131-139): relations r1, r2 get an edge of

@@ -149,6 +149,15 @@ def test_sparse_first_layer_equals_frontier_plus_dense_epilogue(monkeypatch, cas
         assert got.shape == want.shape and torch.equal(got, want), "max |diff| %.3g" % (got - want).abs().max()
         again = UF.first_layer_forward(csr, relation, (node, value), *args)          # the row list is rebuilt every launch
         assert torch.equal(again, want)
+        # round 6: vocabularies beyond LDS (S-stress: 1 000 relations) take frontier_kernel -- relation rows through L2 -- which lists
+        # its rows too; knob bit 0 selects it here
+        lib = UF._lib.load()
+        lib.ultra_rspmm_force_general_path(1)
+        try:
+            general = UF.first_layer_forward(csr, relation, (node, value), *args)
+        finally:
+            lib.ultra_rspmm_force_general_path(0)
+        assert general is not None and torch.equal(general, want), "the L2-row frontier kernel's listed first layer differs"
     run_prefix, max_runs = csr.frontier_runs
     assert run_prefix.dtype == torch.int32 and run_prefix.shape == (csr.n_edges,) and int(run_prefix[-1]) >= max_runs > 0
     assert touched < n * Q                                                            # (some rows really are the constant)

@@ -77,6 +77,19 @@ def test_fused_layer_equals_rspmm_plus_epilogue(case):
                                             float((got - want).abs().max()), int((got != want).any(-1).sum()))
             again = UF.layer_forward(csr, relation, x, boundary, w, b, gamma, beta, 1e-5, relu, shortcut)
             assert torch.equal(got, again)
+            # the last layer's form: the score head inside the same launch == layer + ultra_score_forward_f32
+            query = torch.randn(n_query, 64, device=dev, generator=gen)
+            w1 = torch.randn(128, 128, device=dev, generator=gen) * 0.1
+            b1 = torch.randn(128, device=dev, generator=gen) * 0.1
+            w2 = torch.randn(1, 128, device=dev, generator=gen) * 0.1
+            b2 = torch.randn(1, device=dev, generator=gen)
+            want_score = UF.score_all_entities(want, query, w1, b1, w2, b2)
+            got_score = UF.layer_score_forward(csr, relation, x, boundary, w, b, gamma, beta, 1e-5, relu, shortcut, query, w1, b1, w2, b2)
+            assert got_score is not None and got_score.shape == want_score.shape
+            torch.cuda.synchronize()
+            assert torch.equal(got_score, want_score), (case, float((got_score - want_score).abs().max()), int((got_score != want_score).sum()))
+            assert torch.equal(got_score, UF.layer_score_forward(csr, relation, x, boundary, w, b, gamma, beta, 1e-5, relu, shortcut, query,
+                                                                 w1, b1, w2, b2))
     finally:
         lib.ultra_rspmm_force_general_path(0)
 

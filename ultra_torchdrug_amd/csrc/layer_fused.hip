@@ -96,10 +96,25 @@ struct LayerParams {
     int relu, shortcut;
     long long F;
     int n_rows, n_rel, n_rel_lds, n_tiles, split, n_slots, blocks_per_label;
+    // SCORE (the LAST layer of full-batch evaluation): the score head runs on the finished rows inside the same flush and only
+    // the scores leave -- s_w1 [128, 128] (its hidden half [:, :64] is used here), s_qbias [n_query, 128] = the queries' share of
+    // the head's first layer (score_qbias_kernel), s_w2 [128], s_b2 [1], score [n_query, n_rows]
+    const float *s_w1, *s_qbias, *s_w2;
+    const float *s_b2;      // [1]
+    float *score;
+    int n_query;
 };
 
-template <bool UNIT_W, int REL, int G>
+// LDS of the SCORE form, behind the tiles (it reads its relation rows through L2)
+constexpr uint32_t kOffSW1 = kOffRel;                       // [8 n][4 t4][64 lanes][4] floats: B operands of the head's first layer
+constexpr uint32_t kOffSW2 = kOffSW1 + 128 * 64 * 4;        // [128]
+constexpr uint32_t kOffSMeta = kOffSW2 + 512;               // [waves][16] byte offset of every staged row's score (or ~0)
+constexpr uint32_t kOffSC = kOffSMeta + kLfWaves * 64;      // [n_query][128] the queries' share
+constexpr int kScoreMaxQueries = 32;
+
+template <bool UNIT_W, int REL, int G, bool SCORE = false>
 __global__ __launch_bounds__(kLfBlock) void rowgroup_layer_kernel(const LayerParams p) {
+    static_assert(!SCORE || REL == kRelL2, "the score form keeps its LDS for the head's weights");
     constexpr int U = 16;
     constexpr bool REL_LDS = REL == kRelLds, REL_PART = REL == kRelPart;
     constexpr int W = 4 * G;                                // columns per tile
@@ -130,6 +145,18 @@ __global__ __launch_bounds__(kLfBlock) void rowgroup_layer_kernel(const LayerPar
         lds_raw[kOffGamma / 4 + threadIdx.x] = p.gamma != nullptr ? p.gamma[threadIdx.x] : 1.0f;
         lds_raw[kOffBeta / 4 + threadIdx.x] = p.gamma != nullptr ? p.beta[threadIdx.x] : 0.0f;
         lds_raw[kOffBias / 4 + threadIdx.x] = p.lin_b[threadIdx.x];
+    }
+    if constexpr (SCORE) {
+        for (int idx = threadIdx.x; idx < 128 * 64; idx += kLfBlock) {
+            const int u = idx & 3, l = (idx >> 2) & 63, t4 = (idx >> 8) & 3, n = idx >> 10;
+            const int k = l >> 4, j = l & 15;
+            // step t of the chain  c, hid[0], hid[32], hid[1], hid[33], ...  (score_kernel's order): K = (hid[s], hid[32 + s], hid[s + 1],
+            // hid[33 + s]), s = 2 t
+            lds_raw[kOffSW1 / 4 + idx] = p.s_w1[(16 * n + j) * 128 + 32 * (k & 1) + (k >> 1) + 2 * (4 * t4 + u)];
+        }
+        if (threadIdx.x < 128) lds_raw[kOffSW2 / 4 + threadIdx.x] = p.s_w2[threadIdx.x];
+        if (threadIdx.x < kLfWaves * 16) reinterpret_cast<uint32_t *>(lds_raw)[kOffSMeta / 4 + threadIdx.x] = 0xffffffffu;
+        for (int idx = threadIdx.x; idx < p.n_query * 128; idx += kLfBlock) lds_raw[kOffSC / 4 + idx] = p.s_qbias[idx];
     }
     __syncthreads();
 
@@ -188,18 +215,27 @@ __global__ __launch_bounds__(kLfBlock) void rowgroup_layer_kernel(const LayerPar
         const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<char *>(p.out) + (unsigned long long)row_begin * row_bytes, 0, (int)(uint32_t)part_bytes, 0x00020000);
         const uint32_t lane_off = (uint32_t)(col0 * 4);
+        __amdgpu_buffer_rsrc_t rsrc_score = rsrc_out;
+        if constexpr (SCORE)
+            rsrc_score = __builtin_amdgcn_make_buffer_rsrc(p.score, 0, (int)(uint32_t)((unsigned long long)p.n_query * p.n_rows * 4ull), 0x00020000);
+        const int tile_q0 = tile_id * (W / 64);             // first query block of this column tile
+        const uint32_t meta = kOffSMeta + (uint32_t)wave * 64u;
         __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): the loop is entered with no load pending
         qf4 xv[U], rv[U];
         float wv[U];
         uint32_t cid[U], rid[U];
         auto issue = [&](int n_here, int w_col, int w_rel, float w_w) {
+            // (an opaque copy of the group's base: `base + 4 u` then folds into the instruction's offset field; derived outside
+            // the loop the sixteen addresses were hoisted into sixteen registers)
+            int bpb = bp_base;
+            asm volatile("" : "+v"(bpb));
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                cid[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * u, w_col);
-                rid[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * u, w_rel);
+                cid[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(bpb + 4 * u, w_col);
+                rid[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(bpb + 4 * u, w_rel);
                 wv[u] = 1.0f;
                 if constexpr (!UNIT_W)
-                    wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_base + 4 * u, __builtin_bit_cast(int, w_w)));
+                    wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bpb + 4 * u, __builtin_bit_cast(int, w_w)));
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -240,13 +276,16 @@ __global__ __launch_bounds__(kLfBlock) void rowgroup_layer_kernel(const LayerPar
             // everything else is an immediate offset of the instruction
             uint32_t tl = tile;
             asm volatile("" : "+v"(tl));
-            const uint32_t bias_addr = kOffBias + (uint32_t)i16 * 4u;
+            uint32_t bias_addr = kOffBias + (uint32_t)i16 * 4u;
+            asm volatile("" : "+v"(bias_addr));
             const uint32_t a_addr = tl + (uint32_t)(i16 * kLfStride + 64 * (kq & 1) + 32 * (kq >> 1)) * 4u;     // A operand: row i16, group kq
-            const uint32_t w_addr = kOffW + (uint32_t)lane * 16u;                                               // B operand
+            uint32_t w_addr = kOffW + (uint32_t)lane * 16u;                                                     // B operand
+            asm volatile("" : "+v"(w_addr));
             const uint32_t d_addr = tl + (uint32_t)(4 * kq * kLfStride + i16) * 4u;                             // D: rows 4 kq + r, column i16
             const uint32_t zrow = tl + (uint32_t)((lane >> 1) * kLfStride + 64 + 32 * (lane & 1)) * 4u;         // LayerNorm: row lane / 2, half lane % 2
             const uint32_t irow = tl + (uint32_t)((lane >> 1) * kLfStride + 16 * (lane & 1)) * 4u;
-            const uint32_t gb_addr = kOffGamma + (uint32_t)(32 * (lane & 1)) * 4u;
+            uint32_t gb_addr = kOffGamma + (uint32_t)(32 * (lane & 1)) * 4u;
+            asm volatile("" : "+v"(gb_addr));
             const uint32_t o_addr = tl + (uint32_t)(kq * kLfStride + 4 * i16) * 4u;                             // rows 4 q + kq, this lane's columns
             qf4 acc[4];
 #pragma unroll
@@ -330,6 +369,67 @@ __global__ __launch_bounds__(kLfBlock) void rowgroup_layer_kernel(const LayerPar
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (SCORE) {
+                // ---- the score head on the 16 finished rows (score_kernel's arithmetic, csrc/dense.inc):
+                //   h[o] = relu(c[query][o] + W1[o, :64] . hidden)   chain  c, hid[0], hid[32], hid[1], hid[33], ...  on the matrix cores
+                //   score = b2 + sum over o ascending of h[o] w2[o]   one lane per row, fmaf chain
+                const uint32_t a2_addr = tl + (uint32_t)(i16 * kLfStride + 64 + 32 * (kq & 1)) * 4u;
+                uint32_t w1_addr = kOffSW1 + (uint32_t)lane * 16u;
+                uint32_t c_addr = kOffSC + (uint32_t)(tile_q0 * 128 + i16) * 4u;
+                asm volatile("" : "+v"(w1_addr), "+v"(c_addr));            // (one base each + immediates: see `tl`)
+                const bool odd = (kq >> 1) != 0;
+                // two passes of 64 outputs (16 accumulator registers at a time beside the gather window in flight); the first pass
+                // writes h[0 .. 63] over the rows' consumed input / update halves, the second h[64 .. 127] over the hidden rows it
+                // has just read
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    qf4 acc2[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)        // D row 4 kq + r = iteration kq, staged row r: query block r % (G / 16) of the tile
+                            acc2[n][r] = lds_read1f(c_addr + (uint32_t)(((r % (G / 16)) * 128 + 64 * half + 16 * n) * 4));
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {             // steps t = 2 m, 2 m + 1: hidden columns 4 m .. 4 m + 3 of the lane's half
+                        const qf4 a = lds_read4(a2_addr + (uint32_t)m * 16u);
+                        const float a0 = odd ? a.y : a.x, a1 = odd ? a.w : a.z;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const qf2 b = *(__attribute__((address_space(3))) const qf2 *)(w1_addr + (uint32_t)((((4 * half + n) * 4 + (m >> 1)) * 64) * 16 + (m & 1) * 8));
+                            acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc2[n], 0, 0, 0);
+                            acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc2[n], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (second pass: the hidden rows are consumed)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc2[n][r];
+                            lds_write1(tl + (uint32_t)((4 * kq + r) * kLfStride + 64 * half + 16 * n + i16) * 4u, v > 0.0f ? v : 0.0f);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 16) {
+                    float sc = p.s_b2[0];
+                    const uint32_t hrow = tl + (uint32_t)(lane * kLfStride) * 4u;
+#pragma unroll 8
+                    for (int o4 = 0; o4 < 32; ++o4) {
+                        const qf4 v = lds_read4(hrow + (uint32_t)o4 * 16u), w2 = lds_read4(kOffSW2 + (uint32_t)o4 * 16u);
+                        sc = __builtin_fmaf(v.x, w2.x, sc);
+                        sc = __builtin_fmaf(v.y, w2.y, sc);
+                        sc = __builtin_fmaf(v.z, w2.z, sc);
+                        sc = __builtin_fmaf(v.w, w2.w, sc);
+                    }
+                    const uint32_t off = *(__attribute__((address_space(3))) const uint32_t *)(meta + (uint32_t)lane * 4u);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, sc), rsrc_score, off, 0, 0);
+                    *(__attribute__((address_space(3))) uint32_t *)(meta + (uint32_t)lane * 4u) = 0xffffffffu;      // a ragged last batch must not store it again
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                return;
+            }
             // the finished rows: iteration q's four rows in one 1-KiB store, every lane at the offset its own row has in `out`
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -384,17 +484,37 @@ __global__ __launch_bounds__(kLfBlock) void rowgroup_layer_kernel(const LayerPar
             const uint32_t off_now = live ? (uint32_t)((unsigned long long)(cur_row - row_begin) * row_bytes) + lane_off : 0xffffffffu;
 #pragma unroll
             for (int q = 0; q < 4; ++q) st_off[q] = (q == k_filled) ? off_now : st_off[q];
+            if constexpr (SCORE) {
+                // where the staged row's score goes: score[query, node] (the first lane of every 16-lane group says it)
+                if (i16 == 0)
+                    *(__attribute__((address_space(3))) uint32_t *)(meta + (uint32_t)(4 * k_filled + kq) * 4u) =
+                        live ? (uint32_t)(((unsigned long long)(col0 / 64) * (unsigned long long)p.n_rows + (unsigned long long)cur_row) * 4ull) : 0xffffffffu;
+            }
             ++k_filled;
         }
         if (k_filled > 0) flush();
     }
 }
 
-template <int G>
+// the queries' share of the score head's first layer: c[b, o] = b1[o] + W1[o, 64:] . query[b], the fmaf chain of
+// score_query_bias_kernel (csrc/dense.inc): k = 64, 96, 65, 97, ... from the bias
+__global__ __launch_bounds__(128) void score_qbias_kernel(const float *query, const float *w1, const float *b1, float *qbias) {
+    const int b = blockIdx.x, o = threadIdx.x;
+    const float *w = w1 + o * 128 + 64;
+    const float *q = query + (long long)b * 64;
+    float acc = b1[o];
+    for (int s = 0; s < 32; ++s) {
+        acc = __builtin_fmaf(q[s], w[s], acc);
+        acc = __builtin_fmaf(q[32 + s], w[32 + s], acc);
+    }
+    qbias[(long long)b * 128 + o] = acc;
+}
+
+template <int G, bool SCORE = false>
 int launch_layer_g(const LayerParams &p, bool unit_w, int rel, int grid, size_t lds, hipStream_t stream) {
 #define ULTRA_LF(UW, RL)                                                                                          \
     do {                                                                                                          \
-        auto kern = rowgroup_layer_kernel<UW, RL, G>;                                                             \
+        auto kern = rowgroup_layer_kernel<UW, RL, G, SCORE>;                                                      \
         static bool attr_set[16] = {};                                                                            \
         int dev = 0;                                                                                              \
         HIP_TRY(hipGetDevice(&dev));                                                                              \
@@ -407,13 +527,16 @@ int launch_layer_g(const LayerParams &p, bool unit_w, int rel, int grid, size_t 
         HIP_TRY(hipGetLastError());                                                                               \
         return ULTRA_OK;                                                                                          \
     } while (0)
-    if (unit_w) {
-        if (rel == kRelLds) ULTRA_LF(true, kRelLds);
-        if (rel == kRelPart) ULTRA_LF(true, kRelPart);
-        ULTRA_LF(true, kRelL2);
+    if constexpr (!SCORE) {
+        if (unit_w) {
+            if (rel == kRelLds) ULTRA_LF(true, kRelLds);
+            if (rel == kRelPart) ULTRA_LF(true, kRelPart);
+        } else {
+            if (rel == kRelLds) ULTRA_LF(false, kRelLds);
+            if (rel == kRelPart) ULTRA_LF(false, kRelPart);
+        }
     }
-    if (rel == kRelLds) ULTRA_LF(false, kRelLds);
-    if (rel == kRelPart) ULTRA_LF(false, kRelPart);
+    if (unit_w) ULTRA_LF(true, kRelL2);
     ULTRA_LF(false, kRelL2);
 #undef ULTRA_LF
 }
@@ -438,29 +561,14 @@ int ultra_layer_forward_supported(const ultra_segments *fwd, int64_t n_query, in
     return 1;
 }
 
-int ultra_layer_forward_f32(const ultra_segments *fwd, const float *relation, const float *input, const int32_t *boundary_node,
-                            const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
-                            const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut, float *out,
-                            int64_t n_rel, void *stream) {
-    if (fwd == nullptr) return ULTRA_ERR_NULL_POINTER;
-    if (!abi_ok(fwd)) return ULTRA_ERR_ABI;
-    if (!ultra_layer_forward_supported(fwd, n_query, n_rel)) return ULTRA_ERR_BAD_SHAPE;
-    if (relation == nullptr || input == nullptr || weight == nullptr || bias == nullptr || out == nullptr) return ULTRA_ERR_NULL_POINTER;
-    if ((boundary_node == nullptr) != (boundary_value == nullptr)) return ULTRA_ERR_NULL_POINTER;
-    if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
-    if (out == input) return ULTRA_ERR_BAD_SHAPE;                        // other workgroups still gather from the input
-    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(input) | reinterpret_cast<uintptr_t>(relation) |
-         reinterpret_cast<uintptr_t>(boundary_value)) & 15u)
-        return ULTRA_ERR_BAD_SHAPE;
+// shared by the two entries: tiling, LDS budget, launch.  `score` != NULL: the last layer with the score head inside.
+static int layer_launch(const ultra_segments *fwd, LayerParams &q, int64_t n_query, int64_t n_rel, bool score, hipStream_t s) {
     int n_cu = 0;
     int rc = ultra_detail::persistent_cus(&n_cu);
     if (rc) return rc;
-    LayerParams q{};
     const long long F = n_query * 64;
     q.row_ptr = fwd->row_ptr; q.col = fwd->node_a; q.rel = fwd->rel; q.weight = fwd->weight;
-    q.relation = relation; q.gather = input; q.bnode = boundary_node; q.bvec = boundary_value; q.out = out;
-    q.lin_w = weight; q.lin_b = bias; q.gamma = ln_weight; q.beta = ln_bias; q.eps = ln_eps; q.relu = relu; q.shortcut = shortcut;
-    q.F = F; q.n_rows = (int)fwd->n_rows; q.n_rel = (int)n_rel;
+    q.F = F; q.n_rows = (int)fwd->n_rows; q.n_rel = (int)n_rel; q.n_query = (int)n_query;
     // groups as wide as the row allows when the gathered matrix lives in DRAM (launch_rowgroup's rule), a whole number of tiles
     const bool dram = ultra_detail::wide_groups_forced() || (double)fwd->n_rows * (double)F * 4.0 > 256.0 * 1024 * 1024;
     const int group = (dram && F % 256 == 0) ? 64 : ((dram && F % 128 == 0) ? 32 : 16);
@@ -471,6 +579,14 @@ int ultra_layer_forward_f32(const ultra_segments *fwd, const float *relation, co
     q.n_slots = q.n_tiles * q.split;
     q.blocks_per_label = (n_cu + kXcd - 1) / kXcd;
     const int grid = q.blocks_per_label * kXcd;
+    const bool unit_w = fwd->weight == nullptr;
+    if (score) {
+        const size_t lds = kOffSC + (size_t)n_query * 128 * sizeof(float);
+        q.n_rel_lds = 0;
+        if (group == 64) return launch_layer_g<64, true>(q, unit_w, kRelL2, grid, lds, s);
+        if (group == 32) return launch_layer_g<32, true>(q, unit_w, kRelL2, grid, lds, s);
+        return launch_layer_g<16, true>(q, unit_w, kRelL2, grid, lds, s);
+    }
     // relation rows in the LDS the epilogue leaves: all of them, or the first ones when that is at least a quarter of the table
     const size_t room = (size_t)kMaxLdsBytes - kOffRel;
     const size_t lds_need = (size_t)n_rel * width * sizeof(float);
@@ -483,11 +599,62 @@ int ultra_layer_forward_f32(const ultra_segments *fwd, const float *relation, co
         const int part_rows = (int)(room / ((size_t)width * sizeof(float)));
         if ((long long)part_rows * 4 >= n_rel) { rel = kRelPart; q.n_rel_lds = part_rows; lds += (size_t)part_rows * width * sizeof(float); }
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool unit_w = fwd->weight == nullptr;
     if (group == 64) return launch_layer_g<64>(q, unit_w, rel, grid, lds, s);
     if (group == 32) return launch_layer_g<32>(q, unit_w, rel, grid, lds, s);
     return launch_layer_g<16>(q, unit_w, rel, grid, lds, s);
+}
+
+static int layer_args_ok(const ultra_segments *fwd, const float *relation, const float *input, const int32_t *boundary_node,
+                         const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                         const float *ln_weight, const float *ln_bias, int64_t n_rel) {
+    if (fwd == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (!abi_ok(fwd)) return ULTRA_ERR_ABI;
+    if (!ultra_layer_forward_supported(fwd, n_query, n_rel)) return ULTRA_ERR_BAD_SHAPE;
+    if (relation == nullptr || input == nullptr || weight == nullptr || bias == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if ((boundary_node == nullptr) != (boundary_value == nullptr)) return ULTRA_ERR_NULL_POINTER;
+    if (ln_weight != nullptr && ln_bias == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if ((reinterpret_cast<uintptr_t>(input) | reinterpret_cast<uintptr_t>(relation) | reinterpret_cast<uintptr_t>(boundary_value)) & 15u)
+        return ULTRA_ERR_BAD_SHAPE;
+    return ULTRA_OK;
+}
+
+int ultra_layer_forward_f32(const ultra_segments *fwd, const float *relation, const float *input, const int32_t *boundary_node,
+                            const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                            const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut, float *out,
+                            int64_t n_rel, void *stream) {
+    int rc = layer_args_ok(fwd, relation, input, boundary_node, boundary_value, n_query, weight, bias, ln_weight, ln_bias, n_rel);
+    if (rc) return rc;
+    if (out == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (out == input || (reinterpret_cast<uintptr_t>(out) & 15u)) return ULTRA_ERR_BAD_SHAPE;      // other workgroups still gather from the input
+    LayerParams q{};
+    q.relation = relation; q.gather = input; q.bnode = boundary_node; q.bvec = boundary_value; q.out = out;
+    q.lin_w = weight; q.lin_b = bias; q.gamma = ln_weight; q.beta = ln_bias; q.eps = ln_eps; q.relu = relu; q.shortcut = shortcut;
+    return layer_launch(fwd, q, n_query, n_rel, false, static_cast<hipStream_t>(stream));
+}
+
+int ultra_layer_score_supported(const ultra_segments *fwd, int64_t n_query, int64_t n_rel) {
+    return ultra_layer_forward_supported(fwd, n_query, n_rel) && n_query <= kScoreMaxQueries &&
+           n_query * fwd->n_rows * 4 < (1LL << 32) - 65536;
+}
+
+int ultra_layer_score_forward_f32(const ultra_segments *fwd, const float *relation, const float *input, const int32_t *boundary_node,
+                                  const float *boundary_value, int64_t n_query, const float *weight, const float *bias,
+                                  const float *ln_weight, const float *ln_bias, float ln_eps, int relu, int shortcut,
+                                  const float *query, const float *w1, const float *b1, const float *w2, const float *b2,
+                                  float *qbias, float *score, int64_t n_rel, void *stream) {
+    int rc = layer_args_ok(fwd, relation, input, boundary_node, boundary_value, n_query, weight, bias, ln_weight, ln_bias, n_rel);
+    if (rc) return rc;
+    if (!ultra_layer_score_supported(fwd, n_query, n_rel)) return ULTRA_ERR_BAD_SHAPE;
+    if (query == nullptr || w1 == nullptr || b1 == nullptr || w2 == nullptr || b2 == nullptr || qbias == nullptr || score == nullptr)
+        return ULTRA_ERR_NULL_POINTER;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(score_qbias_kernel, dim3((unsigned)n_query), dim3(128), 0, s, query, w1, b1, qbias);
+    HIP_TRY(hipGetLastError());
+    LayerParams q{};
+    q.relation = relation; q.gather = input; q.bnode = boundary_node; q.bvec = boundary_value; q.out = score;      // (`out` only backs an unused descriptor)
+    q.lin_w = weight; q.lin_b = bias; q.gamma = ln_weight; q.beta = ln_bias; q.eps = ln_eps; q.relu = relu; q.shortcut = shortcut;
+    q.s_w1 = w1; q.s_qbias = qbias; q.s_w2 = w2; q.s_b2 = b2; q.score = score;
+    return layer_launch(fwd, q, n_query, n_rel, true, s);
 }
 
 }  // extern "C"

@@ -916,6 +916,18 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
         // the write acknowledgements of the tile just stored, every iteration.
         if constexpr (BND == 3) {
             // every row back to where it came from; empty slots store past the descriptor (rows * 256 B < 4 GiB: host check)
+            if (p.rows * 256 >= (1LL << 32) - 65536) {
+                // outputs beyond a buffer descriptor's 4 GiB (S-stress: 20 M rows and more): plain stores behind the row test --
+                // the list is a few dozen rows there, what the waits cost does not matter
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = 4 * q + (lane >> 4), c = (lane & 15) * 4;
+                    const f32x4 d = *reinterpret_cast<const f32x4 *>(tile + r * kCbStride + 64 + c);
+                    if (rid[q] >= 0) *reinterpret_cast<f32x4 *>(p.out + (long long)rid[q] * 64 + c) = d;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                continue;
+            }
             const __amdgpu_buffer_rsrc_t rsrc_all = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(uint32_t)(p.rows * 256), 0x00020000);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -1781,9 +1793,9 @@ int ultra_rspmm_frontier_f32(const ultra_segments *by_src, const int32_t *src_pt
 // Sparse first layer of a Bellman-Ford in inference (see include/ultra_rspmm.h): constant row broadcast + slot layout ->
 // frontier kernel (rows + their list) -> epilogue over the listed rows.  Three launches, all kernels (capturable).
 int ultra_first_layer_sparse_supported(int64_t n_dst, int64_t n_rel, int64_t n_query) {
-    return n_query > 0 && n_query <= kCbLdsQueries && n_rel > 0 &&
-           (size_t)n_rel * kTile * sizeof(float) <= (size_t)kMaxLdsBytes && n_dst > 0 &&
-           n_dst * n_query * 256 < (1LL << 32) - 65536 && n_dst * n_query < 0x7fffffffLL && !g_force_general;
+    // (round 6: vocabularies beyond LDS take frontier_kernel -- it lists its rows too -- and outputs beyond 4 GiB plain stores
+    // in the listed epilogue: S-stress, 1 000 relations, 20 M rows and more)
+    return n_query > 0 && n_query <= kCbLdsQueries && n_rel > 0 && n_dst > 0 && n_dst * n_query < 0x7fffffffLL;
 }
 
 // `update` == `out`: inference (the epilogue runs in place on the listed rows).  Training passes its own `update` buffer: it
@@ -1843,12 +1855,20 @@ static int first_layer_sparse_impl(const ultra_segments *by_src, const int32_t *
     for (int sh = 0; sh < 31; ++sh)
         if ((1LL << sh) == by_src->piece_len) p.piece_shift = sh;
     p.run_prefix = run_prefix; p.row_list = row_list; p.list_offset = list_offset; p.list_len = (int)row_list_len;
-    p.slices = kFrontierLdsSlices;
     const size_t msg_bytes = (size_t)n_rel * kTile * sizeof(float);
-    const int fgrid = (int)n_query * p.slices;
-    rc = by_src->weight == nullptr ? launch_with_lds(frontier_lds_kernel<true>, p, fgrid, msg_bytes, s, kFrontierLdsThreads)
-                                   : launch_with_lds(frontier_lds_kernel<false>, p, fgrid, msg_bytes, s, kFrontierLdsThreads);
-    if (rc) return rc;
+    if (!g_force_general && msg_bytes <= (size_t)kMaxLdsBytes) {
+        p.slices = kFrontierLdsSlices;
+        const int fgrid = (int)n_query * p.slices;
+        rc = by_src->weight == nullptr ? launch_with_lds(frontier_lds_kernel<true>, p, fgrid, msg_bytes, s, kFrontierLdsThreads)
+                                       : launch_with_lds(frontier_lds_kernel<false>, p, fgrid, msg_bytes, s, kFrontierLdsThreads);
+        if (rc) return rc;
+    } else {                                    // vocabulary beyond LDS (or knob bit 0): relation rows through L2
+        p.slices = 64;
+        const dim3 fgrid((unsigned)n_query, (unsigned)p.slices);
+        if (by_src->weight == nullptr) hipLaunchKernelGGL(frontier_kernel<true>, fgrid, dim3(kFrontierThreads), 0, s, p);
+        else hipLaunchKernelGGL(frontier_kernel<false>, fgrid, dim3(kFrontierThreads), 0, s, p);
+        HIP_TRY(hipGetLastError());
+    }
     // (3) the epilogue on the listed rows (in place in inference)
     cp.update = update; cp.out = out; cp.rows = n_dst * n_query; cp.row_list = row_list; cp.list_count = list_offset + n_query;
     cp.list_len = (int)row_list_len;

@@ -326,6 +326,8 @@ def first_layer_train_forward(csr, relation, boundary, weight, bias, ln_weight=N
 # Entity layers in inference as ONE launch (rspmm + epilogue, csrc/layer_fused.hip) on plans that run one row per lane group
 # (big graphs: row pointers, no split rows).  ULTRA_FUSED_LAYER=0: the two launches (same bits).
 FUSED_LAYER = __import__("os").environ.get("ULTRA_FUSED_LAYER", "1") != "0"
+# ... and the last layer with the score head inside the same launch (ULTRA_FUSED_SCORE=0: layer launch + score launch)
+FUSED_SCORE = __import__("os").environ.get("ULTRA_FUSED_SCORE", "1") != "0"
 
 
 def layer_forward(csr, relation, input, boundary, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True,
@@ -360,6 +362,42 @@ def layer_forward(csr, relation, input, boundary, weight, bias, ln_weight=None, 
             ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
             out.data_ptr(), n_rel, _stream()))
     return out
+
+
+def layer_score_forward(csr, relation, input, boundary, weight, bias, ln_weight, ln_bias, ln_eps, relu, shortcut, query, w1, b1, w2,
+                        b2):
+    """The LAST entity layer of full-batch evaluation AND the score head in one launch: ``score_all_entities(layer_forward(...),
+    query, w1, b1, w2, b2)`` bit for bit -- scores ``(Q, N)`` -- with the layer's ``(N, Q, 64)`` output never reaching memory
+    (/root/reference/ultra/model.py:120-138,177-193).  ``None`` where the entry does not apply (the caller runs the two calls)."""
+    if not FUSED_LAYER or not FUSED_SCORE or input.dim() != 3 or input.shape[-1] != 64:
+        return None
+    n_dst, n_src, n_rel = csr.shape
+    n_query = input.shape[1]
+    lib = _lib.load()
+    plan = csr.fwd
+    if n_dst != n_src or input.shape[0] != n_src or not lib.ultra_layer_score_supported(plan.pointer, n_query, n_rel):
+        return None
+    F = n_query * 64
+    b_node, b_value = (None, None) if boundary is None else boundary
+    tensors = [relation, input, weight, bias, query, w1, b1, w2, b2] + ([ln_weight, ln_bias] if ln_weight is not None else []) \
+        + ([b_value] if b_value is not None else [])
+    if (tuple(relation.shape) != (n_rel, F) or tuple(weight.shape) != (64, 128) or tuple(w1.shape) != (128, 128) or w2.numel() != 128
+            or b2.numel() != 1 or tuple(query.shape) != (n_query, 64)
+            or any(t.dtype != torch.float32 or not t.is_cuda or t.device != input.device for t in tensors)
+            or (b_node is not None and (b_node.dtype != torch.int32 or tuple(b_node.shape) != (n_query,) or tuple(b_value.shape) != (n_query, 64)))):
+        return None
+    relation, input = relation.contiguous(), input.contiguous()
+    score = torch.empty(n_query, n_src, dtype=torch.float32, device=input.device)
+    qbias = torch.empty(n_query, 128, dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        _lib.check(lib.ultra_layer_score_forward_f32(
+            plan.pointer, relation.data_ptr(), input.data_ptr(), b_node.contiguous().data_ptr() if b_node is not None else None,
+            b_value.contiguous().data_ptr() if b_value is not None else None, n_query, weight.contiguous().data_ptr(),
+            bias.contiguous().data_ptr(), ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
+            ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
+            query.contiguous().data_ptr(), w1.contiguous().data_ptr(), b1.contiguous().data_ptr(), w2.contiguous().data_ptr(),
+            b2.contiguous().data_ptr(), qbias.data_ptr(), score.data_ptr(), n_rel, _stream()))
+    return score
 
 
 # Relation-graph layers in inference as ONE launch where the plan carries its dense form (ultra_dense_layer_forward_f32).

@@ -283,7 +283,14 @@ class TransferNBFNet(nn.Module):
                     hidden = ops.combine_forward(None, update, w, b, g, beta, eps, relu, self.short_cut, reuse_update=True,
                                                  input_boundary=boundary)
             else:
-                # big graphs (one row per lane group): rspmm and epilogue in one launch, `update` never in memory; same bits
+                # big graphs (one row per lane group): rspmm and epilogue in one launch, `update` never in memory; same bits --
+                # and the LAST layer with the score head inside too: only the (2B, N) scores leave
+                if i == len(stack) - 1:
+                    first, second = self.mlp.layers
+                    score = ops.layer_score_forward(csr, tables[i], hidden, boundary, w, b, g, beta, eps, relu, self.short_cut, query,
+                                                    first.weight, first.bias, second.weight, second.bias)
+                    if score is not None:
+                        return score
                 fused = ops.layer_forward(csr, tables[i], hidden, boundary, w, b, g, beta, eps, relu, self.short_cut)
                 if fused is not None:
                     hidden = fused
