@@ -31,6 +31,14 @@ def main(path, out):
                 got += "; gradient all-reduce exposed %.2f ms per step (mode %s)" % (c["allreduce_exposed_ms_per_step"], c.get("step_mode"))
         else:
             got = "operator fwd %.2f ms = %.2e edges/s = %.3f of the 8 TB/s HBM peak" % (c["operator_fwd_ms"], c["edges_per_s"], c["frac_of_hbm_peak"])
+            if "predict_ms" in c:
+                lb = c.get("layer_breakdown_b1", {})
+                got += ("; INFERENCE: whole predict %.1f ms for one triple (2 queries), %.1f ms for four; one entity layer %.2f ms as ONE launch = %.3f of "
+                        "the HBM peak on its %.1f GB (two launches: %.2f + %.2f ms); filtered rank %.2f ms; operator at B = 4 %.1f ms = %.3f"
+                        % (c["predict_ms"], c["predict_ms_b4"], lb.get("layer_ms", float("nan")), c.get("frac_of_hbm_peak_whole_layer", float("nan")),
+                           lb.get("layer_algorithmic_bytes", 0) / 1e9, lb.get("two_launch_rspmm_ms", float("nan")),
+                           lb.get("two_launch_epilogue_ms", float("nan")), c.get("filtered_rank_ms", float("nan")),
+                           c.get("operator_b4_ms", float("nan")), c.get("operator_b4_frac", float("nan"))))
         rows.append("| %d | %s | %s | %s |" % (k, c["name"], c["shape"], got))
     head = ("Per-config timings of `%s` (one `bench.py` run under rocprofv3; headline: %.3f ms per evaluation batch, "
             "%.3e entity-graph edge messages/s).\n\n" % (path.split("/")[-1], j["ms_per_step"], j["value"]))

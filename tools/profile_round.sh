@@ -8,6 +8,8 @@
 #   <tag>_stress_rowgroup_pmc.txt / <tag>_kbench_fwd_pmc.txt   the counter means those come from
 #   <tag>_train_{wn18rr,fb15k237}_kernel_stats.csv + _step.txt   fine-tuning steps (hipGraph replays): kernel summary, ms/step
 #   <tag>_step_trace_{fb15k237,codexs}.txt   one evaluation batch, kernel by kernel (rocprofv3 --kernel-trace)
+#   <tag>_stress_predict_kernel_stats.csv + _b1.json / _b4.json   config 5 as inference: whole predict on S-stress (round 6)
+#   <tag>_pmc_layer_fused_raw.txt        PMC A/B of one S-stress layer, fused launch vs two launches (tools/pmc_layer_fused.sh)
 # usage (gpurun): bash tools/profile_round.sh r03
 tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -33,6 +35,13 @@ for wl in fb15k237 codexs; do
   "$PY" tools/debug/step_trace_report.py "$d" > "$out/${tag}_step_trace_${wl}.txt" 2>&1
   rm -rf "$out/step_$wl"
 done
+# BASELINE config 5 as inference (round 6): the whole predict on S-stress, kernel by kernel; and the PMC A/B of one layer, fused vs two launches
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stress_predict" -o sp -- "$PY" tools/stress_predict.py --batch 1 --reps 3 --json "$out/${tag}_stress_predict_b1.json" > "$out/stress_predict.log" 2>&1
+find "$out/stress_predict" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_stress_predict_kernel_stats.csv" \;
+rm -rf "$out/stress_predict"
+timeout 300 "$PY" tools/stress_predict.py --batch 4 --reps 3 --json "$out/${tag}_stress_predict_b4.json" > "$out/stress_predict_b4.log" 2>&1
+bash tools/pmc_layer_fused.sh "$out/pmc_layer" 2 > "$out/${tag}_pmc_layer_fused_raw.txt" 2>&1
+rm -rf "$out/pmc_layer"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $pass --output-format csv -d "$out/stress_$name" -- "$PY" tools/stress_bench.py --reps 2 --knob 0 > "$out/stress_$name.log" 2>&1
