@@ -64,6 +64,14 @@ def test_whole_model_inference_on_the_stress_graph(oracle):
                 hidden = ops.combine_forward(hidden, update.view(N, n_query, 64), w, b, g, beta, eps, relu, model.short_cut,
                                              reuse_update=False)
             hiddens.append(hidden)
+            if i == 0:
+                # the sparse first layer (1 000 relations: the L2-row frontier kernel lists the rows; 5.1 GB of output: plain stores
+                # in the listed epilogue) against the frontier kernel + the dense boundary-form epilogue, over ALL 20 M rows
+                update = ops.rspmm_frontier(csr, tables[0], boundary).view(N, n_query, 64)
+                dense0 = ops.combine_forward(None, update, w, b, g, beta, eps, relu, model.short_cut, reuse_update=True,
+                                             input_boundary=boundary)
+                assert torch.equal(hidden, dense0), "sparse first layer differs from the dense form at size"
+                del update, dense0
         first, second = model.mlp.layers
         scores = ops.score_all_entities(hidden, query, first.weight, first.bias, second.weight, second.bias)      # (2, N)
         assert torch.equal(scores.view(2, 1, N).transpose(0, 1), pred), "the op-by-op replay is not what predict computes"
