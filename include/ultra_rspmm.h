@@ -696,6 +696,25 @@ int ultra_layer_forward_f32(const ultra_segments *fwd, const float *relation, co
                             int64_t n_rel, void *stream);
 
 /*
+ * The SECOND entity layer of a Bellman-Ford in inference on such plans (ABI 8).  After ultra_first_layer_sparse_f32 every row of
+ * the first layer's output is ONE constant vector except the rows it LISTED (a few dozen on a graph like S-stress: the boundary
+ * nodes' out-neighbours), and the second layer's rspmm gathers that output once per edge.  ultra_second_layer_sources writes, for
+ * every edge of the forward plan, the row to gather: the edge's own source if it is listed, ONE fixed unlisted row otherwise --
+ * the same values, the same sums (results bit for bit), and all but a few hundred of the 100 M gathers hit the cache.
+ *   col: the forward plan's node_a [n_edges (+ slack readable words)];  row_list / list_count / list_len: as written by
+ *   ultra_first_layer_sparse_f32 (row ids node * n_query + query, -1 = empty; the count on the device);  bitmap: uint32
+ *   [(n_node + 31) / 32] scratch;  c_node: int32 [1] scratch;  sources: int32 [n_edges + slack] out.  Needs list_len + 1 < n_node.
+ * ultra_layer_forward_sources_f32 = ultra_layer_forward_f32 gathering row sources[e] for edge e.
+ */
+int ultra_second_layer_sources(const int32_t *col, int64_t n_edges, int64_t slack, const int32_t *row_list, const int32_t *list_count,
+                               int64_t list_len, int64_t n_query, int64_t n_node, uint32_t *bitmap, int32_t *c_node,
+                               int32_t *sources, void *stream);
+int ultra_layer_forward_sources_f32(const ultra_segments *fwd, const int32_t *sources, const float *relation, const float *input,
+                                    const int32_t *boundary_node, const float *boundary_value, int64_t n_query, const float *weight,
+                                    const float *bias, const float *ln_weight, const float *ln_bias, float ln_eps, int relu,
+                                    int shortcut, float *out, int64_t n_rel, void *stream);
+
+/*
  * The LAST entity layer of full-batch evaluation with the score head inside the same launch (ABI 8; csrc/layer_fused.hip):
  *     score[q, n] = w2 . relu(W1 . cat[hidden_L[n, q], query[q]] + b1) + b2,   hidden_L = ultra_layer_forward_f32(...)
  * = ultra_layer_forward_f32 followed by ultra_score_forward_f32 (/root/reference/ultra/model.py:134-138,177-193 after the last

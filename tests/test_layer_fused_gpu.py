@@ -94,6 +94,42 @@ def test_fused_layer_equals_rspmm_plus_epilogue(case):
         lib.ultra_rspmm_force_general_path(0)
 
 
+def test_second_layer_with_remapped_sources_equals_the_plain_layer(monkeypatch):
+    """After the sparse first layer all but the LISTED rows of the layer's output hold one constant vector; the second layer then
+    gathers, for every edge whose source is not listed, ONE fixed unlisted row (`ultra_second_layer_sources`): the same values, so
+    the same bits as the layer over the plan's own sources -- with hubs, repeated and isolated boundary nodes."""
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    dev = _dev()
+    monkeypatch.setattr(UF, "SPARSE_FIRST_LAYER_MIN_ROWS", 0)
+    n, e, r = 30000, 150000, 12
+    g = random_graph(seed=9, n_node=n, n_edge=e, n_rel=r)
+    g["src"][:25] = 17                                        # node 17: 25 out-edges
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    csr = RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), None, n, n, r, wide_ids=True, piece_len=512)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    for nodes in ([17, 3], [17, 17, 29999, 0]):
+        Q = len(nodes)
+        relation = torch.randn(r, 64 * Q, device=dev, generator=gen)
+        relation2 = torch.randn(r, 64 * Q, device=dev, generator=gen)
+        boundary = (torch.tensor(nodes, dtype=torch.int32, device=dev), torch.randn(Q, 64, device=dev, generator=gen))
+        w, b, gamma, beta = _layer_params(gen, dev)
+        first = UF.first_layer_forward(csr, relation, boundary, w, b, gamma, beta, 1e-5, True, True, want_list=True)
+        assert first is not None
+        hidden1, row_list, list_count = first
+        sources = UF.second_layer_sources(csr, row_list, list_count, Q)
+        assert sources is not None and sources.shape == csr.fwd.node_a.shape
+        E = csr.n_edges
+        plain_src = csr.fwd.node_a[:E]
+        moved = sources[:E] != plain_src
+        assert 0.9 * E < int(moved.sum()) < E                          # almost every edge gathers the one constant row ...
+        assert len(torch.unique(sources[:E][moved])) == 1              # ... the same one
+        assert torch.equal(hidden1[sources[:E].long()], hidden1[plain_src.long()])      # and it holds what the edge's own source holds
+        w2, b2, gamma2, beta2 = _layer_params(gen, dev)
+        want = UF.layer_forward(csr, relation2, hidden1, boundary, w2, b2, gamma2, beta2, 1e-5, True, True)
+        got = UF.layer_forward(csr, relation2, hidden1, boundary, w2, b2, gamma2, beta2, 1e-5, True, True, sources=sources)
+        assert torch.equal(got, want)
+
+
 def test_fused_layer_declines_what_it_does_not_cover():
     from ultra_torchdrug_amd import RelCSR, functional as UF
     dev = _dev()

@@ -124,6 +124,8 @@ EXPORTS = (
     "ultra_dense_layer_forward_f32",
     "ultra_layer_forward_supported",
     "ultra_layer_forward_f32",
+    "ultra_second_layer_sources",
+    "ultra_layer_forward_sources_f32",
     "ultra_layer_score_supported",
     "ultra_layer_score_forward_f32",
 )
@@ -160,6 +162,10 @@ def load():
     lib.ultra_layer_forward_supported.argtypes = [seg, i64, i64]
     lib.ultra_layer_forward_f32.restype = i32
     lib.ultra_layer_forward_f32.argtypes = [seg, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, vp]
+    lib.ultra_second_layer_sources.restype = i32
+    lib.ultra_second_layer_sources.argtypes = [vp, i64, i64, vp, vp, i64, i64, i64, vp, vp, vp, vp]
+    lib.ultra_layer_forward_sources_f32.restype = i32
+    lib.ultra_layer_forward_sources_f32.argtypes = [seg, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.c_float, i32, i32, vp, i64, vp]
     lib.ultra_layer_score_supported.restype = i32
     lib.ultra_layer_score_supported.argtypes = [seg, i64, i64]
     lib.ultra_layer_score_forward_f32.restype = i32

@@ -496,6 +496,43 @@ __global__ __launch_bounds__(kLfBlock) void rowgroup_layer_kernel(const LayerPar
     }
 }
 
+// ---- ultra_second_layer_sources: a bitmap of the listed nodes, one unlisted node, the remapped source of every edge
+__global__ void sources_zero_kernel(uint32_t *bits, long long n_words) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) bits[i] = 0u;
+}
+
+__global__ void sources_mark_kernel(const int32_t *row_list, const int32_t *list_count, int list_len, int n_query, uint32_t *bits) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int count = list_count[0] < list_len ? list_count[0] : list_len;
+    if (slot >= count) return;
+    const int row = row_list[slot];                        // node * n_query + query, or -1
+    if (row < 0) return;
+    const int node = row / n_query;
+    atomicOr(bits + (node >> 5), 1u << (node & 31));
+}
+
+__global__ void sources_pick_kernel(const uint32_t *bits, int n_cand, int32_t *c_node) {
+    if (threadIdx.x != 0) return;
+    int pick = 0;
+    for (int node = 0; node < n_cand; ++node)
+        if (!((bits[node >> 5] >> (node & 31)) & 1u)) { pick = node; break; }
+    c_node[0] = pick;
+}
+
+__global__ __launch_bounds__(256) void sources_remap_kernel(const int32_t *col, long long n_edges, long long total, const uint32_t *bits,
+                                                            const int32_t *c_node, int32_t *sources) {
+    const int c = c_node[0];
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        int v = 0;                                          // (the slack behind the last edge: readable, never used)
+        if (e < n_edges) {
+            const int u = col[e];
+            v = ((bits[u >> 5] >> (u & 31)) & 1u) ? u : c;
+        }
+        sources[e] = v;
+    }
+}
+
 // the queries' share of the score head's first layer: c[b, o] = b1[o] + W1[o, 64:] . query[b], the fmaf chain of
 // score_query_bias_kernel (csrc/dense.inc): k = 64, 96, 65, 97, ... from the bias
 __global__ __launch_bounds__(128) void score_qbias_kernel(const float *query, const float *w1, const float *b1, float *qbias) {
@@ -562,12 +599,13 @@ int ultra_layer_forward_supported(const ultra_segments *fwd, int64_t n_query, in
 }
 
 // shared by the two entries: tiling, LDS budget, launch.  `score` != NULL: the last layer with the score head inside.
-static int layer_launch(const ultra_segments *fwd, LayerParams &q, int64_t n_query, int64_t n_rel, bool score, hipStream_t s) {
+static int layer_launch(const ultra_segments *fwd, LayerParams &q, int64_t n_query, int64_t n_rel, bool score, hipStream_t s,
+                        const int32_t *col_override = nullptr) {
     int n_cu = 0;
     int rc = ultra_detail::persistent_cus(&n_cu);
     if (rc) return rc;
     const long long F = n_query * 64;
-    q.row_ptr = fwd->row_ptr; q.col = fwd->node_a; q.rel = fwd->rel; q.weight = fwd->weight;
+    q.row_ptr = fwd->row_ptr; q.col = col_override != nullptr ? col_override : fwd->node_a; q.rel = fwd->rel; q.weight = fwd->weight;
     q.F = F; q.n_rows = (int)fwd->n_rows; q.n_rel = (int)n_rel; q.n_query = (int)n_query;
     // groups as wide as the row allows when the gathered matrix lives in DRAM (launch_rowgroup's rule), a whole number of tiles
     const bool dram = ultra_detail::wide_groups_forced() || (double)fwd->n_rows * (double)F * 4.0 > 256.0 * 1024 * 1024;
@@ -630,6 +668,46 @@ int ultra_layer_forward_f32(const ultra_segments *fwd, const float *relation, co
     q.relation = relation; q.gather = input; q.bnode = boundary_node; q.bvec = boundary_value; q.out = out;
     q.lin_w = weight; q.lin_b = bias; q.gamma = ln_weight; q.beta = ln_bias; q.eps = ln_eps; q.relu = relu; q.shortcut = shortcut;
     return layer_launch(fwd, q, n_query, n_rel, false, static_cast<hipStream_t>(stream));
+}
+
+// The same layer with the gathered row of every edge taken from `sources` instead of the plan (see ultra_second_layer_sources).
+int ultra_layer_forward_sources_f32(const ultra_segments *fwd, const int32_t *sources, const float *relation, const float *input,
+                                    const int32_t *boundary_node, const float *boundary_value, int64_t n_query, const float *weight,
+                                    const float *bias, const float *ln_weight, const float *ln_bias, float ln_eps, int relu,
+                                    int shortcut, float *out, int64_t n_rel, void *stream) {
+    int rc = layer_args_ok(fwd, relation, input, boundary_node, boundary_value, n_query, weight, bias, ln_weight, ln_bias, n_rel);
+    if (rc) return rc;
+    if (out == nullptr || sources == nullptr) return ULTRA_ERR_NULL_POINTER;
+    if (out == input || (reinterpret_cast<uintptr_t>(out) & 15u)) return ULTRA_ERR_BAD_SHAPE;
+    LayerParams q{};
+    q.relation = relation; q.gather = input; q.bnode = boundary_node; q.bvec = boundary_value; q.out = out;
+    q.lin_w = weight; q.lin_b = bias; q.gamma = ln_weight; q.beta = ln_bias; q.eps = ln_eps; q.relu = relu; q.shortcut = shortcut;
+    return layer_launch(fwd, q, n_query, n_rel, false, static_cast<hipStream_t>(stream), sources);
+}
+
+// ---- sources of the SECOND layer.  After the sparse first layer (ultra_first_layer_sparse_f32) every row of the layer's output is
+// ONE constant vector except the LISTED rows (a few dozen on a graph like S-stress).  The second layer gathers that output once
+// per edge -- 100 M random 512-byte rows of which all but a few hundred hold the same bytes.  Pointing every edge whose source is
+// NOT listed at ONE fixed unlisted row makes those gathers cache hits: identical values, identical sums, no DRAM gather.
+int ultra_second_layer_sources(const int32_t *col, int64_t n_edges, int64_t slack, const int32_t *row_list, const int32_t *list_count,
+                               int64_t list_len, int64_t n_query, int64_t n_node, uint32_t *bitmap, int32_t *c_node,
+                               int32_t *sources, void *stream) {
+    if (n_edges < 0 || slack < 0 || list_len < 0 || n_query <= 0 || n_node <= 0 || n_node > 0x7fffffffLL || n_edges > 0x7fffffffLL)
+        return ULTRA_ERR_BAD_SHAPE;
+    if (list_len + 1 >= n_node) return ULTRA_ERR_BAD_SHAPE;            // (some node among 0 .. list_len must be unlisted)
+    if (col == nullptr || row_list == nullptr || list_count == nullptr || bitmap == nullptr || c_node == nullptr || sources == nullptr)
+        return ULTRA_ERR_NULL_POINTER;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n_words = (n_node + 31) / 32;
+    hipLaunchKernelGGL(sources_zero_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, bitmap, n_words);
+    hipLaunchKernelGGL(sources_mark_kernel, dim3((unsigned)((list_len + 255) / 256 > 0 ? (list_len + 255) / 256 : 1)), dim3(256), 0, s,
+                       row_list, list_count, (int)list_len, (int)n_query, bitmap);
+    hipLaunchKernelGGL(sources_pick_kernel, dim3(1), dim3(64), 0, s, bitmap, (int)(list_len + 1), c_node);
+    const long long total = n_edges + slack;
+    const unsigned blocks = (unsigned)((total + 256 * 4 - 1) / (256 * 4) < 65535 * 16 ? (total + 256 * 4 - 1) / (256 * 4) : 65535 * 16);
+    hipLaunchKernelGGL(sources_remap_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, col, (long long)n_edges, total, bitmap, c_node, sources);
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
 }
 
 int ultra_layer_score_supported(const ultra_segments *fwd, int64_t n_query, int64_t n_rel) {

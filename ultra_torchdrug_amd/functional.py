@@ -229,7 +229,7 @@ SPARSE_FIRST_LAYER_TRAIN_MAX_BYTES = int(__import__("os").environ.get("ULTRA_SPA
 
 
 def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True,
-                        shortcut=False):
+                        shortcut=False, want_list=False):
     """The whole FIRST Bellman-Ford layer in inference -- ``rspmm_frontier`` followed by ``combine_forward(None, update, ...,
     input_boundary=boundary)``, bit for bit -- with the epilogue on the rows the frontier reaches only: every other row of the
     layer's output is one constant vector (``relu(LN(bias))``; ``ultra/model.py:116-127``), computed once and broadcast.
@@ -268,6 +268,8 @@ def first_layer_forward(csr, relation, boundary, weight, bias, ln_weight=None, l
             ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
             ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
             out.data_ptr(), row_list.data_ptr(), row_list.numel(), int(max_runs), list_offset.data_ptr(), n_dst, n_rel, _stream()))
+    if want_list:           # (out, the rows that differ from the layer's constant row, their count on the device): second_layer_sources
+        return out, row_list, list_offset[n_query:]
     return out
 
 
@@ -330,8 +332,41 @@ FUSED_LAYER = __import__("os").environ.get("ULTRA_FUSED_LAYER", "1") != "0"
 FUSED_SCORE = __import__("os").environ.get("ULTRA_FUSED_SCORE", "1") != "0"
 
 
+# The SECOND layer's gathers when the first layer was sparse: all but the listed rows of its input hold one constant vector, so
+# every edge whose source is not listed gathers ONE fixed unlisted row instead (cache hits; same bits).  ULTRA_SECOND_LAYER_SOURCES=0:
+# the plan's own sources.  Taken where the list is at most 1 / 64 of the nodes (beyond that the remapped gathers are DRAM
+# gathers again and the pass over the edges that builds them is pure cost).
+SECOND_LAYER_SOURCES = __import__("os").environ.get("ULTRA_SECOND_LAYER_SOURCES", "1") != "0"
+
+
+def second_layer_sources(csr, row_list, list_count, n_query):
+    """int32 ``(E + slack,)``: for every edge of the forward plan the row the SECOND layer gathers -- the edge's own source when
+    the sparse first layer listed it (``row_list`` / ``list_count`` of ``first_layer_forward(want_list=True)``), one fixed
+    unlisted row otherwise (``ultra_second_layer_sources``).  ``None`` where it does not apply (plans the fused layer does not
+    take, lists that are not small against the node count)."""
+    if not SECOND_LAYER_SOURCES or not FUSED_LAYER:
+        return None
+    n_dst, n_src, n_rel = csr.shape
+    plan = csr.fwd
+    lib = _lib.load()
+    if (n_dst != n_src or not lib.ultra_layer_forward_supported(plan.pointer, n_query, n_rel)
+            or row_list.numel() * 64 > n_src or row_list.numel() + 1 >= n_src):
+        return None
+    dev = row_list.device
+    E = plan.n_edges
+    slack = plan.node_a.numel() - E
+    sources = torch.empty(E + slack, dtype=torch.int32, device=dev)
+    bitmap = torch.empty((n_src + 31) // 32, dtype=torch.int32, device=dev)
+    c_node = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.ultra_second_layer_sources(plan.node_a.data_ptr(), E, slack, row_list.data_ptr(), list_count.data_ptr(),
+                                                  row_list.numel(), n_query, n_src, bitmap.data_ptr(), c_node.data_ptr(),
+                                                  sources.data_ptr(), _stream()))
+    return sources
+
+
 def layer_forward(csr, relation, input, boundary, weight, bias, ln_weight=None, ln_bias=None, ln_eps=1e-5, relu=True,
-                  shortcut=False):
+                  shortcut=False, sources=None):
     """``[input +] relu(LN(Linear(cat[input, rspmm(csr, relation, input, "add", "mul") + boundary])))`` -- one entity layer of a
     Bellman-Ford in inference (/root/reference/ultra/layer.py:298-392, ultra/model.py:126-127) -- in ONE launch where the forward
     plan runs one row per lane group: ``rspmm_forward(..., boundary=)`` + ``combine_forward`` bit for bit, without the ``update``
@@ -354,6 +389,18 @@ def layer_forward(csr, relation, input, boundary, weight, bias, ln_weight=None, 
         return None
     relation, input = relation.contiguous(), input.contiguous()
     out = torch.empty_like(input)
+    if sources is not None:
+        if sources.dtype != torch.int32 or sources.numel() != plan.node_a.numel() or sources.device != input.device:
+            raise RuntimeError("layer_forward: sources must be second_layer_sources() of this plan")
+        with torch.cuda.device(input.device):
+            _lib.check(lib.ultra_layer_forward_sources_f32(
+                plan.pointer, sources.data_ptr(), relation.data_ptr(), input.data_ptr(),
+                b_node.contiguous().data_ptr() if b_node is not None else None,
+                b_value.contiguous().data_ptr() if b_value is not None else None, n_query, weight.contiguous().data_ptr(),
+                bias.contiguous().data_ptr(), ln_weight.contiguous().data_ptr() if ln_weight is not None else None,
+                ln_bias.contiguous().data_ptr() if ln_weight is not None else None, float(ln_eps), int(bool(relu)), int(bool(shortcut)),
+                out.data_ptr(), n_rel, _stream()))
+        return out
     with torch.cuda.device(input.device):
         _lib.check(lib.ultra_layer_forward_f32(
             plan.pointer, relation.data_ptr(), input.data_ptr(), b_node.contiguous().data_ptr() if b_node is not None else None,

@@ -272,12 +272,14 @@ class TransferNBFNet(nn.Module):
         boundary = (anchor32, query)
         n_node = und.num_node
         hidden = None
+        listed = None
         for i, entry in enumerate(stack):
             w, b, g, beta, eps, relu = entry["combine"]
             if i == 0:
                 # the whole first layer from the sparse boundary: epilogue on the rows the frontier reaches, one constant
                 # vector everywhere else (same bits as the two calls below, which remain for shapes it does not take)
-                hidden = ops.first_layer_forward(csr, tables[0], boundary, w, b, g, beta, eps, relu, self.short_cut)
+                first_out = ops.first_layer_forward(csr, tables[0], boundary, w, b, g, beta, eps, relu, self.short_cut, want_list=True)
+                hidden, listed = (None, None) if first_out is None else (first_out[0], first_out[1:])
                 if hidden is None:
                     update = ops.rspmm_frontier(csr, tables[0], boundary).view(n_node, n_query, 64)
                     hidden = ops.combine_forward(None, update, w, b, g, beta, eps, relu, self.short_cut, reuse_update=True,
@@ -291,7 +293,10 @@ class TransferNBFNet(nn.Module):
                                                     first.weight, first.bias, second.weight, second.bias)
                     if score is not None:
                         return score
-                fused = ops.layer_forward(csr, tables[i], hidden, boundary, w, b, g, beta, eps, relu, self.short_cut)
+                # (the SECOND layer gathers the sparse first layer's output: one constant row but for the listed rows -- its
+                # edges' sources are re-pointed at one unlisted row wherever the source is not listed: cache hits, same bits)
+                sources = ops.second_layer_sources(csr, listed[0], listed[1], n_query) if (i == 1 and listed is not None) else None
+                fused = ops.layer_forward(csr, tables[i], hidden, boundary, w, b, g, beta, eps, relu, self.short_cut, sources=sources)
                 if fused is not None:
                     hidden = fused
                     continue
