@@ -347,11 +347,13 @@ def stress_inference(task, csr, gen, n_node, n_base_rel):
             e.record()
             marks.append((name, e))
 
+        forms_equal = None
         for rep in range(2):                                           # the second pass is the measured one
             marks.clear()
             mark("start")
             w, b, g, beta, eps, relu = stack[0]["combine"]
-            hidden = ops.first_layer_forward(csr, tables[0], boundary, w, b, g, beta, eps, relu, model.short_cut)
+            first_out = ops.first_layer_forward(csr, tables[0], boundary, w, b, g, beta, eps, relu, model.short_cut, want_list=True)
+            hidden, listed = (None, None) if first_out is None else (first_out[0], first_out[1:])
             if hidden is None:
                 update = ops.rspmm_frontier(csr, tables[0], boundary).view(n_node, 2, 64)
                 hidden = ops.combine_forward(None, update, w, b, g, beta, eps, relu, model.short_cut, reuse_update=True,
@@ -359,12 +361,29 @@ def stress_inference(task, csr, gen, n_node, n_base_rel):
             mark("first_layer")
             for i in range(1, len(stack)):
                 w, b, g, beta, eps, relu = stack[i]["combine"]
-                if i == 1:                                             # layer 2 as the TWO launches the fused kernel replaces (A/B)
+                if i == 1:
+                    # layer 2 three ways on the same input: the TWO launches the fused kernel replaces (A/B), the fused launch, and
+                    # the fused launch with the constant-row sources predict uses after a sparse first layer -- equal bits required
                     update = ops.rspmm_forward(csr, tables[i], hidden.flatten(1), "add", "mul", boundary=boundary)
                     mark("rspmm_%d" % (i + 1))
-                    hidden = ops.combine_forward(hidden, update.view(n_node, 2, 64), w, b, g, beta, eps, relu, model.short_cut,
-                                                 reuse_update=True)
+                    split = ops.combine_forward(hidden, update.view(n_node, 2, 64), w, b, g, beta, eps, relu, model.short_cut,
+                                                reuse_update=True)
                     mark("epilogue_%d" % (i + 1))
+                    fused = ops.layer_forward(csr, tables[i], hidden, boundary, w, b, g, beta, eps, relu, model.short_cut)
+                    mark("layer_%d" % (i + 1))
+                    again = None
+                    if fused is not None:
+                        sources = ops.second_layer_sources(csr, listed[0], listed[1], 2) if listed is not None else None
+                        mark("second_layer_sources")
+                        if sources is not None:
+                            again = ops.layer_forward(csr, tables[i], hidden, boundary, w, b, g, beta, eps, relu, model.short_cut,
+                                                      sources=sources)
+                            mark("layer_2_constant_sources")
+                        forms_equal = bool(torch.equal(fused, split)) and (again is None or bool(torch.equal(again, split)))
+                    del fused, again
+                    hidden = split
+                    del update, split
+                    mark("(comparisons)")
                     continue
                 if i == len(stack) - 1:                                # the last layer with the score head inside, as predict runs it
                     first, second = model.mlp.layers
@@ -392,7 +411,7 @@ def stress_inference(task, csr, gen, n_node, n_base_rel):
         steps = {name: marks[k - 1][1].elapsed_time(e) for k, (name, e) in enumerate(marks) if k > 0}
         rspmm = float(np.median([v for k, v in steps.items() if k.startswith("rspmm_")]))
         epi = float(np.median([v for k, v in steps.items() if k.startswith("epilogue_")]))
-        fused_ms = [v for k, v in steps.items() if k.startswith("layer_")]
+        fused_ms = [v for k, v in steps.items() if k.startswith("layer_") and not k.startswith("layer_2")]
         F = 128
         split_bytes = bytes_algo(E, n_node, R, F) + 3 * n_node * F * 4
         fused_bytes = bytes_algo(E, n_node, R, F) + 1 * n_node * F * 4            # the `update` rows neither written nor read
@@ -402,6 +421,9 @@ def stress_inference(task, csr, gen, n_node, n_base_rel):
                            "layer_kernel": "rowgroup_layer_kernel (rspmm + epilogue in one launch, csrc/layer_fused.hip)" if fused_ms
                                            else "rowgroup_kernel + combine_kernel",
                            "two_launch_rspmm_ms": rspmm, "two_launch_epilogue_ms": epi, "two_launch_layer_ms": rspmm + epi,
+                           "second_layer_constant_sources_ms": steps.get("layer_2_constant_sources"),
+                           "second_layer_sources_build_ms": steps.get("second_layer_sources"),
+                           "layer_2_forms_bit_identical": forms_equal,
                            "score_head_ms": steps.get("score_head"),
                            "last_layer_with_score_head_ms": steps.get("last_layer_with_score_head"), "steps_ms": steps,
                            "layer_algorithmic_bytes": layer_bytes, "two_launch_layer_algorithmic_bytes": split_bytes,
@@ -411,7 +433,8 @@ def stress_inference(task, csr, gen, n_node, n_base_rel):
                            "bytes": "one layer = rspmm's algorithmic bytes at F = 128 (E (4F + 12) + 4NF + 4RF + 4(N + 1)) + the epilogue's "
                                     "own streams: the rows' input segments in (N F 4; the output rows are the rspmm's) when fused, input + "
                                     "update in and output out (3 N F 4) as two launches; stream events on the launch stream between eager "
-                                    "calls; layer 2 runs as two launches for the A/B, layers 3-6 fused (median)"}
+                                    "calls; layer 2 runs three ways on the same input (two launches, fused, fused with the constant-row sources predict uses: "
+                                    "`layer_2_forms_bit_identical`), layers 3-5 fused (median), the last layer with the score head"}
     return out
 
 
