@@ -220,7 +220,7 @@ def latest_profile(pattern):
         return None, None
 
 
-def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel=500):
+def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel=500, cpu_leg=True):
     """Config 5 at size: S-stress -- uniform triples + inverse edges => E = 100 M, R = 1 000, 64d.
     (i) the operator at B = 1 (the gathered matrix, 2.56 GB, cannot live in any cache: the HBM roofline of the path) and at
     B = 4 (`b4`: 1-KiB gathers, 64 lanes per row); (ii) what BASELINE calls this config -- INFERENCE: the whole `predict` of the
@@ -277,7 +277,8 @@ def stress_roofline(dev, lib, n_node=10_000_000, n_triple=50_000_000, n_base_rel
           "edges_per_s": 4 * E / (ms4 * 1e-3)}
     inference = stress_inference(task, csr, gen, n_node, n_base_rel)
     inference["task_build_s"] = task_s
-    cpu = stress_cpu_baseline(csr, plan, n_node, R)
+    # (the CPU leg: rank 0 at N = 1 only, as the contract's cpu_baseline)
+    cpu = stress_cpu_baseline(csr, plan, n_node, R) if cpu_leg else {"skipped": "N > 1 or --no-cpu-baseline"}
     # the keys the driver's record keeps come first: the contract's six, then what THIS box delivers ("confirm on the
     # box with a copy / gather calibration, report both") -- `frac` moves 0.65 <-> 0.70 with the box, `frac_of_gather` says how much
     # of that is the box and how much the kernel
@@ -1362,7 +1363,7 @@ def main():
         if pretrain_n is not None:
             configs.append(pretrain_n)
         if args.stress:                             # rank 0 of any world: the other ranks wait at the final barrier
-            roofline = stress_roofline(dev, lib)
+            roofline = stress_roofline(dev, lib, cpu_leg=(world == 1 and not args.no_cpu_baseline))
             roofline["l2"] = l2_line
             inf = roofline["inference"]
             configs.append({"config": 5, "name": "Synthetic KG 10M nodes / 100M edges / 1k relations, 64d inference (HBM-roofline stress)",
