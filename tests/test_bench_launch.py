@@ -48,8 +48,9 @@ def test_world_size_that_contradicts_gpus_is_refused():
 @pytest.mark.gpu
 def test_gpus_2_launches_its_own_ranks_and_times_the_pretraining_step_with_the_reducer():
     share = {} if torch.cuda.device_count() >= 2 else {"ULTRA_BENCH_SHARE_GPU": "1"}
-    run, lines = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--no-stress", "--no-cpu-baseline", "--mrr-queries", "0"],
-                      env=dict(share, WORLD_SIZE="", RANK="", LOCAL_RANK=""))
+    # (config 5 runs on a graph of 1 / 30 the size here: two ranks share one GPU on this box)
+    run, lines = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--stress-shape", "300000,1500000,40", "--no-cpu-baseline",
+                       "--mrr-queries", "0"], env=dict(share, WORLD_SIZE="", RANK="", LOCAL_RANK=""))
     assert run.returncode == 0 and len(lines) == 1, (run.returncode, run.stdout[-1000:], run.stderr[-3000:])
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak" and line["value"] > 0
@@ -65,3 +66,9 @@ def test_gpus_2_launches_its_own_ranks_and_times_the_pretraining_step_with_the_r
     assert cfg["ranks_distinct_devices"] == (2 if two_gpus else 1)
     assert cfg["cfg4_step_modes_agree"] is True and cfg["cfg4_step_mode"] in ("phased", "after")
     assert "[bench rank 0" in run.stderr and "[bench rank 1" in run.stderr          # per-phase progress of every rank
+    # round 6: the first N-rank line also says who ran what -- per-rank exposed all-reduce and step modes -- and carries config 5 on
+    # every rank (replicas, each rank its own triples, no collective in the data path)
+    assert len(four["allreduce_exposed_ms_per_step_per_rank"]) == 2 and len(four["step_modes_per_rank"]) == 2
+    five = [c for c in cfg["configs"] if c["config"] == 5][0]
+    assert five["all_ranks"]["n_gpus"] == 2 == cfg["cfg5_n_gpus"] and len(five["all_ranks"]["per_rank_ms_per_triple"]) == 2
+    assert cfg["cfg5_triples_per_s_all_ranks"] > 0 and five["predict_ms"] > 0
