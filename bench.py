@@ -418,7 +418,10 @@ def stress_inference(task, csr, gen, n_node, n_base_rel):
         fused_bytes = bytes_algo(E, n_node, R, F) + 1 * n_node * F * 4            # the `update` rows neither written nor read
         layer_ms = float(np.median(fused_ms)) if fused_ms else rspmm + epi
         layer_bytes = fused_bytes if fused_ms else split_bytes
+        tlj, tlsrc = latest_profile("traffic_layer_fused.json")
         out["layer_b1"] = {"first_layer_ms": steps["first_layer"], "layer_ms": layer_ms,
+                           "traffic": (tlj.get("hbm_bytes_per_launch") if fused_ms else tlj.get("two_launch_hbm_bytes_per_layer")) if tlj else None,
+                           "traffic_source": tlsrc,
                            "layer_kernel": "rowgroup_layer_kernel (rspmm + epilogue in one launch, csrc/layer_fused.hip)" if fused_ms
                                            else "rowgroup_kernel + combine_kernel",
                            "two_launch_rspmm_ms": rspmm, "two_launch_epilogue_ms": epi, "two_launch_layer_ms": rspmm + epi,
