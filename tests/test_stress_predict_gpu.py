@@ -153,3 +153,27 @@ def test_whole_model_inference_on_the_stress_graph(oracle):
         # measured on an MI355X: max 1.4e-6, mean 6.1e-8 (LayerNorm divides by the row's standard deviation: the errors of the
         # 128-term dot products are amplified by 1 / std)
         assert float(err.max()) <= 1e-5 and float(err.mean()) <= 5e-7, (float(err.max()), float(err.mean()))
+
+
+def test_captured_evaluation_over_a_big_graph_uses_the_fused_layers_and_gives_the_eager_ranks(monkeypatch):
+    """`engine.evaluate` on a stress-shaped graph (2 M nodes / 20 M edges / 100 relations: node ids beyond the packed edge word, so
+    the plans run one row per lane group): `predict` + filtered rank captured as one hipGraph -- sparse first layer through the
+    L2-row frontier kernel, second layer with constant-row sources, fused layers, the last one with the score head -- must give
+    the ranks of eager calls with every round-6 form switched off (two launches per layer, plain sources, score launch)."""
+    from ultra_torchdrug_amd import engine, functional as UF
+    from ultra_torchdrug_amd.data import stress_task
+    dev = torch.device("cuda:0")
+    N, T, R = 2_000_000, 10_000_000, 50
+    task, gen = stress_task(dev, N, T, R)
+    triples = torch.stack([torch.randint(0, N, (12,), device=dev, generator=gen), torch.randint(0, N, (12,), device=dev, generator=gen),
+                           torch.randint(0, R, (12,), device=dev, generator=gen)], dim=1)
+    und = task.model._undirected(task.fact_graph)
+    assert und.relcsr.fwd.row_ptr is not None and und.relcsr.fwd.n_pieces == 0          # the fused layer's kind of plan
+    with torch.no_grad():
+        metrics, ranks = engine.evaluate(task, triples, batch_size=4, graphed=True, cache_relations=False, unique_queries=False)
+        monkeypatch.setattr(UF, "FUSED_LAYER", False)
+        monkeypatch.setattr(UF, "SECOND_LAYER_SOURCES", False)
+        want = torch.cat([task.rank_batch(triples[i:i + 4]) for i in range(0, 12, 4)])
+    assert ranks.shape == (12, 2) and torch.equal(ranks.to(want.device), want), (ranks.tolist(), want.tolist())
+    assert 0.0 < float(metrics["mrr"]) <= 1.0
+
