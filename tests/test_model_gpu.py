@@ -630,6 +630,36 @@ def test_sparse_first_layer_in_training_gives_the_gradients_of_the_dense_layer()
         UF.SPARSE_FIRST_LAYER_MIN_ROWS, UF.SPARSE_FIRST_LAYER_TRAIN_MAX_FRACTION = old_rows, old_fraction
 
 
+def test_relation_stack_tables_as_one_autograd_node_give_the_gradients_of_the_per_layer_expands():
+    """Training, relation stack (rel_model._TiledTables): the six layers' ``relation.weight`` tiled ``B`` times by one autograd
+    node (two launches forward, two backward) instead of an expanding copy forward and a reduction backward per layer
+    (``ultra/layer.py:125-126``).  Same tables -> the loss is identical; every parameter gradient agrees to a sum's rounding."""
+    from ultra_torchdrug_amd import rel_model
+    dev = torch.device("cuda:0")
+    task, triples = _build((1200, 9000, 12))
+    task.num_negative = 32
+    task.to(dev).train()
+    batch = torch.from_numpy(triples[:16]).to(dev)
+    results = {}
+    for tiled in (True, False):
+        rel_model.TILED_TABLES_TRAIN = tiled
+        try:
+            task.zero_grad(set_to_none=True)
+            torch.manual_seed(3)
+            loss, _ = task(batch)
+            loss.backward()
+            results[tiled] = (loss.detach().clone(),
+                              {k: p.grad.detach().clone() for k, p in task.named_parameters() if p.grad is not None})
+        finally:
+            rel_model.TILED_TABLES_TRAIN = True
+    assert torch.equal(results[True][0], results[False][0])
+    g_t, g_e = results[True][1], results[False][1]
+    assert g_t.keys() == g_e.keys() and sum(k.endswith("relation.weight") for k in g_t) == 6
+    for k in g_t:
+        scale = g_e[k].abs().max().item()
+        assert (g_t[k] - g_e[k]).abs().max().item() <= 5e-6 * scale + 1e-12, k
+
+
 def test_sparse_first_layer_backward_survives_a_switch_to_the_full_d_relation_kernels():
     """the sparse first layer's backward writes `d_update` at the listed rows only; every d_relation kernel but the
     boundary one multiplies ALL of its rows (by the zero input row: 0 * NaN of uninitialised memory = NaN).  The forward now takes

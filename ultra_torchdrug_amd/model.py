@@ -121,7 +121,8 @@ class TransferNBFNet(nn.Module):
         if self.query.dim() == 2:
             query = self.query[r_index]
         else:
-            query = self.query[torch.arange(bs, device=graph.device), r_index]
+            # (row r_index[b] of block b; as a gather its backward is one scatter, advanced indexing's is a sort plus ~10 launches)
+            query = self.query.gather(1, r_index.view(bs, 1, 1).expand(bs, 1, self.query.shape[-1])).squeeze(1)
         index = h_index.unsqueeze(-1).expand_as(query)
         boundary = torch.zeros(graph.num_node, *query.shape, device=query.device, dtype=query.dtype)
         boundary.scatter_add_(0, index.unsqueeze(0), query.unsqueeze(0))

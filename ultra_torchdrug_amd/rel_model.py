@@ -10,6 +10,7 @@
 Parameter names follow the reference (``rel_models.0.model.layers.{i}.{linear,layer_norm,relation}``,
 ``rel_models.0.model.mlp.layers.{0,1}``) so checkpoints load unchanged.
 """
+import os
 from collections.abc import Sequence
 
 import torch
@@ -56,6 +57,29 @@ def construct_relation_graph(graph):
     return Graph(torch.cat(edges, dim=0), num_node=n_rel, num_relation=4)
 
 
+TILED_TABLES_TRAIN = os.environ.get("ULTRA_TILED_TABLES_TRAIN", "1") != "0"
+
+
+class _TiledTables(torch.autograd.Function):
+    """``weight.unsqueeze(1).expand(-1, B, -1).flatten(1)`` (layer.py:125-126) of all layers' relation embeddings: two
+    launches forward, two backward (the sum over the B copies of every layer's table gradient at once)."""
+
+    @staticmethod
+    def forward(ctx, batch_size, *weights):
+        n_rel, dim = weights[0].shape
+        ctx.batch_size = batch_size
+        tiled = torch.stack(weights).unsqueeze(2).expand(-1, -1, batch_size, -1).reshape(len(weights), n_rel, batch_size * dim)
+        return tuple(tiled.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = next(g for g in grads if g is not None)
+        dim = live.shape[1] // ctx.batch_size
+        total = torch.stack([torch.zeros_like(live) if g is None else g for g in grads])
+        total = total.view(len(grads), live.shape[0], ctx.batch_size, dim).sum(2)
+        return (None,) + tuple(None if g is None else t for g, t in zip(grads, total.unbind(0)))
+
+
 class CustomNBFNet(nn.Module):
     """``rel_model.py:227-339`` (constructor and module tree; the shipped model is the ``Full`` subclass)."""
 
@@ -84,11 +108,16 @@ class CustomNBFNet(nn.Module):
         """Inference: the query-independent relation tables of all layers (``relation.weight.repeat(1, B)``,
         layer.py:125-126) tiled by ONE copy instead of one per layer."""
         convs = list(self.layers)
-        if torch.is_grad_enabled() or not convs or any(conv.dependent for conv in convs):
+        if not convs or any(conv.dependent for conv in convs):
             return None
         weights = [conv.relation.weight for conv in convs]
         if any(w.shape != weights[0].shape or not w.is_cuda for w in weights):
             return None
+        if torch.is_grad_enabled():
+            # training: the same tiling as ONE autograd node -- per layer it is a copy forward and a reduction backward
+            if not TILED_TABLES_TRAIN or any(w.dtype != torch.float32 for w in weights):
+                return None
+            return {id(conv): table for conv, table in zip(convs, _TiledTables.apply(batch_size, *weights))}
         n_rel, dim = weights[0].shape
         tiled = torch.stack(weights).unsqueeze(2).expand(-1, -1, batch_size, -1).reshape(len(convs), n_rel, batch_size * dim)
         return {id(conv): tiled[i] for i, conv in enumerate(convs)}

@@ -428,6 +428,7 @@ class KnowledgeGraphCompletion(nn.Module):
         all_loss = torch.zeros((), dtype=torch.float32, device=batch.device)
         metric = {}
         pred = self.predict(batch, all_loss, metric)
+        first = True                                        # (nothing on the path adds to `all_loss` before the criteria)
         pos_h_index, pos_t_index, pos_r_index = batch.t()
         names = {"bce": "binary cross entropy", "ce": "cross entropy", "ranking": "ranking loss"}
         for criterion, weight in self.criterion.items():
@@ -458,7 +459,10 @@ class KnowledgeGraphCompletion(nn.Module):
                 loss = (loss * sample_weight).sum() / sample_weight.sum()
             loss = loss.mean()
             metric[names[criterion]] = loss
-            all_loss = all_loss + loss * weight
+            # (`0 + loss * 1` of the shipped configuration without its two launches forward and one backward: the same value)
+            term = loss if weight == 1 else loss * weight
+            all_loss = term if first else all_loss + term
+            first = False
         return all_loss, metric
 
 
