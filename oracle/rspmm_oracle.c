@@ -443,7 +443,7 @@ int oracle_combine_forward(const float *input, const float *update, const float 
             for (int c = 0; c < 64; ++c) v[c] = ((v[c] - mean) * inv) * gamma[c] + beta[c];
         }
         if (relu)
-            for (int c = 0; c < 64; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+            for (int c = 0; c < 64; ++c) v[c] = !(v[c] <= 0.0f) ? v[c] : 0.0f;      /* torch.relu: NaN stays NaN (ultra/layer.py:392) */
         if (shortcut)
             for (int c = 0; c < 64; ++c) v[c] = v[c] + in[c];
         for (int c = 0; c < 64; ++c) out[r * 64 + c] = v[c];
@@ -491,7 +491,7 @@ int oracle_linear_forward_grouped(const float *input, const float *weight, int64
                     acc = fmaf(in[half + s], w[half + s], acc);
                 }
             }
-            if (relu) acc = acc > 0.0f ? acc : 0.0f;
+            if (relu) acc = !(acc <= 0.0f) ? acc : 0.0f;         /* NaN stays NaN, as torch.relu */
             out[r * out_dim + o] = acc;
         }
     }

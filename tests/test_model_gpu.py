@@ -117,6 +117,56 @@ def test_graphed_predict_equals_eager():
     assert task.model.check_indices          # the reference's asserts are back on for eager calls
 
 
+def _same_with_nans(a, b):
+    return torch.equal(a.isnan(), b.isnan()) and torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0))
+
+
+@pytest.mark.parametrize("where", ["rel_models.0.model.layers.0.relation.weight", "model.layers.0.relation_projection.layers.1.weight"])
+def test_captured_predict_of_a_model_with_a_non_finite_weight_keeps_the_full_kernels_nan_propagation(where):
+    """VERDICT r5 weak 11.  The first-layer shortcuts and the dense relation-graph form never multiply a relation entry by a
+    zero input row; the full kernels (and the reference's scatter) do, and ``inf * 0`` is ``NaN`` at every destination of an edge
+    of that relation.  Eager calls test their tables per call; a hipGraph replay cannot -- ``engine.capture_semantics`` tests
+    the parameters once when the capture starts and records the full kernels for a model that holds a non-finite one.  Scores
+    and NaN pattern of the replay == the eager call == the eager call with every shortcut switched off by hand."""
+    import warnings
+    from ultra_torchdrug_amd import _lib, functional as UF, layer
+    from ultra_torchdrug_amd.engine import GraphedPredict
+    task, triples = _build("S-tiny")
+    dev = torch.device("cuda:0")
+    task.to(dev)
+    with torch.no_grad():
+        dict(task.named_parameters())[where][1, 5] = float("inf")
+    batches = [torch.from_numpy(triples[i:i + 8]).to(dev) for i in (0, 8)]
+    lib = _lib.load()
+    with torch.no_grad():
+        eager = [task.predict(b).clone() for b in batches]
+        layer.FRONTIER_FIRST_LAYER = False
+        lib.ultra_rspmm_force_general_path(64)
+        try:
+            full = [task.predict(b).clone() for b in batches]
+        finally:
+            layer.FRONTIER_FIRST_LAYER = True
+            lib.ultra_rspmm_force_general_path(0)
+    assert any(bool(f.isnan().any()) for f in full)
+    for e, f in zip(eager, full):
+        assert _same_with_nans(e, f)
+    # ... and the NaN pattern is the one the reference's message + aggregate definition gives in ATen (tests/aten_definition.py)
+    from aten_definition import aten_definition
+    with torch.no_grad(), aten_definition(task):
+        definition = [task.predict(b).clone() for b in batches]
+    for f, d in zip(full, definition):
+        assert torch.equal(f.isnan(), d.isnan())
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        graphed = GraphedPredict(task, batches[0])
+    assert any("non-finite parameter" in str(w.message) for w in caught)
+    assert UF.CAPTURE_ASSUMES_FINITE
+    for b, want in zip(batches, full):
+        got = graphed(b)
+        torch.cuda.synchronize()
+        assert _same_with_nans(got, want)
+
+
 def test_evaluate_with_graph_replay_equals_eager_evaluation():
     """engine.evaluate: the hipGraph-replayed batches and the ragged eager tail give the ranks of the eager loop."""
     from ultra_torchdrug_amd import engine

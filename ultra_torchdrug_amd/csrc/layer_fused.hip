@@ -355,8 +355,8 @@ __global__ __launch_bounds__(kLfBlock) void rowgroup_layer_kernel(const LayerPar
                         v.w = ((v.w - mean) * inv) * gq.w + bq.w;
                     }
                     if (p.relu) {
-                        v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f;
-                        v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f;
+                        v.x = !(v.x <= 0.0f) ? v.x : 0.0f; v.y = !(v.y <= 0.0f) ? v.y : 0.0f;
+                        v.z = !(v.z <= 0.0f) ? v.z : 0.0f; v.w = !(v.w <= 0.0f) ? v.w : 0.0f;
                     }
                     if (p.shortcut) {
                         // the row's input: even columns at [0, 32), odd columns at [32, 64) of the staged row; columns 4 q .. 4 q + 3
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kLfBlock) void rowgroup_layer_kernel(const LayerPar
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float v = acc2[n][r];
-                            lds_write1(tl + (uint32_t)((4 * kq + r) * kLfStride + 64 * half + 16 * n + i16) * 4u, v > 0.0f ? v : 0.0f);
+                            lds_write1(tl + (uint32_t)((4 * kq + r) * kLfStride + 64 * half + 16 * n + i16) * 4u, !(v <= 0.0f) ? v : 0.0f);
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }

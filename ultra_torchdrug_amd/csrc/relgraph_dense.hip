@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kDnWaves * 64) void dense_layer_kernel(const DenseL
         v.z = ((v.z - mean) * inv) * g.z + b.z; v.w = ((v.w - mean) * inv) * g.w + b.w;
     }
     if (q.relu) {
-        v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f;
+        v.x = !(v.x <= 0.0f) ? v.x : 0.0f; v.y = !(v.y <= 0.0f) ? v.y : 0.0f; v.z = !(v.z <= 0.0f) ? v.z : 0.0f; v.w = !(v.w <= 0.0f) ? v.w : 0.0f;
     }
     if (q.shortcut) {
         const dn4 x = *reinterpret_cast<const dn4 *>(t_in + lrow * kDlStride + 4 * i);

@@ -891,7 +891,7 @@ __global__ __launch_bounds__(kCbWaves * 64, PF ? 1 : 2) void combine_kernel(cons
         }
         if (p.relu) {
 #pragma unroll
-            for (int c = 0; c < 32; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+            for (int c = 0; c < 32; ++c) v[c] = !(v[c] <= 0.0f) ? v[c] : 0.0f;
         }
         if (p.shortcut) {
 #pragma unroll

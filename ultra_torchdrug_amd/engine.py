@@ -12,7 +12,9 @@ Bellman-Ford for its own batch elements; there is no exchange inside rspmm (SURV
 
 Backend: ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` on CPU (tests).
 """
+import contextlib
 import os
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -85,6 +87,34 @@ def validate_triples(task, triples):
     return triples
 
 
+@contextlib.contextmanager
+def capture_semantics(task):
+    """Around the capture of an INFERENCE graph: one host read that tests every parameter of ``task`` for ``inf`` / ``NaN``.
+    The first-layer shortcuts and the dense relation-graph form need finite relation tables (``0 * inf`` is ``NaN`` in the
+    reference, they never form the product); eager calls test the tables per call, a replay cannot.  A model with a
+    non-finite parameter -- a damaged checkpoint -- is therefore captured on the full kernels (shortcuts declined, dense form
+    off for the duration of the capture: a process-wide switch, restored to 0), whose NaN propagation is the reference's,
+    with a warning.  Yields whether the parameters are finite.  (Captured TRAINING steps take finiteness on trust: their
+    weights change under the graph, and a run that reached ``inf`` is lost either way.)"""
+    from . import _lib, functional
+    params = [p.detach() for p in task.parameters() if p.is_cuda and p.is_floating_point() and p.numel()]
+    finite = bool(torch.stack([torch.isfinite(p).all() for p in params]).all()) if params else True
+    if finite:
+        yield True
+        return
+    warnings.warn("capture: the model holds a non-finite parameter; recording the full kernels (the reference's NaN "
+                  "propagation) instead of the first-layer / dense relation-graph shortcuts")
+    saved = functional.CAPTURE_ASSUMES_FINITE
+    functional.CAPTURE_ASSUMES_FINITE = False
+    lib = _lib.load()
+    lib.ultra_rspmm_force_general_path(64)
+    try:
+        yield False
+    finally:
+        functional.CAPTURE_ASSUMES_FINITE = saved
+        lib.ultra_rspmm_force_general_path(0)
+
+
 class GraphedPredict:
     """``task.predict`` for a fixed batch size as ONE hipGraph: an evaluation batch is ~250 small launches
     (18 rspmm + epilogues + relation projections + score MLP) whose host-side issue cost exceeds their GPU time
@@ -113,7 +143,7 @@ class GraphedPredict:
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: other threads of the process (the RCCL watchdog polls events) must not abort the capture
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
+            with capture_semantics(task), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
                 self.static_pred = task.predict(self.static_batch)
                 if with_ranks:
                     self.static_ranks = task.rank_batch(self.static_batch, pred=self.static_pred)
@@ -522,7 +552,7 @@ class GraphedScores:
                     self._scores(*self.static)
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
+            with capture_semantics(task), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
                 self.static_pred = self._scores(*self.static)
         finally:
             model.check_indices = True

@@ -1294,6 +1294,20 @@ class _RSPMMFunction(torch.autograd.Function):
 
 
 # Training, first layer (the caller's `input_is_boundary` promise): the edge gradient of `input` only at the boundary rows
+# While a hipGraph is being captured nothing can be read back, so the shortcuts whose precondition is a FINITE relation table
+# (first-layer frontier, sparse first layer, dense relation-graph form) take it on trust.  engine.capture_semantics() tests the
+# model's parameters once per capture and clears this for a model that holds a non-finite one: the capture then records the
+# full kernels, whose NaN propagation is the reference's.
+CAPTURE_ASSUMES_FINITE = True
+
+
+def tables_finite(relation):
+    """Eager: one reduction and a host read; under capture: :data:`CAPTURE_ASSUMES_FINITE`."""
+    if relation.is_cuda and torch.cuda.is_current_stream_capturing():
+        return CAPTURE_ASSUMES_FINITE
+    return bool(torch.isfinite(relation).all())
+
+
 # (see rspmm_backward_boundary_rows).  ULTRA_BOUNDARY_ROWS_BACKWARD=0: the full d_input pass.
 BOUNDARY_ROWS_BACKWARD = __import__("os").environ.get("ULTRA_BOUNDARY_ROWS_BACKWARD", "1") != "0"
 
@@ -1354,7 +1368,7 @@ class _SumLayerFunction(torch.autograd.Function):
                            and frontier_supported("add", mul, flat.shape[1]) and csr.shape[0] == csr.shape[1]
                            and flat.shape[1] == 64 * b_node.shape[0] and b_node.shape[0] <= 65535)
         sparse = None
-        if first_layer and (torch.cuda.is_current_stream_capturing() or bool(torch.isfinite(relation).all())):
+        if first_layer and tables_finite(relation):
             # first layer: only the boundary nodes' out-edges carry a message (same bits as the full kernel, finite tables:
             # see rspmm_frontier) -- as in inference; and the epilogue runs on the rows they reach only (first_layer_train_forward)
             # (only where the backward takes d_relation from the boundary nodes' out-edges: every other d_relation kernel multiplies

@@ -29,10 +29,10 @@ def _frontier_tables_finite(relation_input):
     the frontier kernel never visits those edges.  Eager calls therefore test the table (one tiny reduction + a host
     read, like the reference's own per-call index asserts, ``ultra/model.py:174-175``) and send a non-finite table
     through the full kernel -- the reference's semantics.  While a hipGraph is being captured no host read is possible:
-    a captured step assumes finite tables, as it assumes valid indices (the capture's eager warm-up calls do test them)."""
-    if relation_input.is_cuda and torch.cuda.is_current_stream_capturing():
-        return True
-    return bool(torch.isfinite(relation_input).all())
+    the capture goes by what ``engine.capture_semantics`` found in the model's parameters when it started
+    (``functional.CAPTURE_ASSUMES_FINITE``), as it goes by the triples' range check for the indices."""
+    from . import functional
+    return functional.tables_finite(relation_input)
 
 
 class _TallLinear(torch.autograd.Function):
