@@ -38,7 +38,7 @@ def main():
         task = build_ultra(r)
         task.preprocess(Graph(torch.from_numpy(triples), num_node=n, num_relation=r))
         task.to(dev).train()
-        opt = torch.optim.AdamW(task.parameters(), lr=5e-4)
+        opt = torch.optim.AdamW(task.parameters(), lr=5e-4, fused=True)       # (bench.make_optimizer)
         reducer = None if mode == "no reducer" else engine.GradientReducer(task, overlap=True, single_rank=True)
         step = engine.GraphedTrainStep(task, opt, batches[0], reducer=reducer, phased=(mode == "phased"))
         assert step.mode == {"no reducer": "single", "after": "after", "phased": "phased"}[mode], step.mode

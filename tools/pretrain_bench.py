@@ -32,7 +32,7 @@ def main():
     for i, name in enumerate(["S-fb15k237", "S-wn18rr", "S-codexm"]):
         task.add_context(str(i), synthetic_kg(name))
     task.to(dev).train()
-    opt = torch.optim.AdamW(task.parameters(), lr=5e-4)
+    opt = torch.optim.AdamW(task.parameters(), lr=5e-4, fused=True)       # (bench.make_optimizer)
     gen = torch.Generator().manual_seed(DEFAULT_SEED + rank)          # seed + rank, script/run_full.py:102-107
     msgs, seen = 0, []
     for step in range(3 + args.steps):
