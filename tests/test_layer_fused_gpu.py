@@ -38,6 +38,8 @@ CASES = {
     "g64_two_tiles": (1501, 12000, 40, 8, 16, False),
     "g32_weights": (2000, 18000, 60, 2, 16, True),
     "g16_rel_l2_weights": (1800, 15000, 900, 1, 0, True),
+    "g64_thirty_two_queries": (700, 5000, 20, 32, 16, False),      # the score form's largest query count, 8 column tiles
+    "g16_three_nodes": (3, 7, 2, 1, 0, False),                    # fewer rows than one batch of four iterations
 }
 
 
@@ -47,9 +49,10 @@ def test_fused_layer_equals_rspmm_plus_epilogue(case):
     dev = _dev()
     n, e, r, n_query, knob, weights = CASES[case]
     g = random_graph(seed=len(case), n_node=n, n_edge=e, n_rel=r, weights=weights)
-    g["dst"][:40] = 7                                     # a row of three windows
-    g["dst"][40:60] = n - 1                               # the last row: two windows
-    keep = g["dst"] != 11                                 # an empty row
+    if n > 60:
+        g["dst"][:40] = 7                                 # a row of three windows
+        g["dst"][40:60] = n - 1                           # the last row: two windows
+    keep = g["dst"] != (11 if n > 60 else 1)              # an empty row
     t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
     csr = RelCSR(t(g["dst"][keep]), t(g["src"][keep]), t(g["rel"][keep]), t(g["w"][keep]) if weights else None, n, n, r,
                  wide_ids=True, piece_len=512)
@@ -59,7 +62,7 @@ def test_fused_layer_equals_rspmm_plus_epilogue(case):
     x = torch.randn(n, n_query, 64, device=dev, generator=gen)
     relation = torch.randn(r, F, device=dev, generator=gen)
     b_node = torch.randint(0, n, (n_query,), device=dev, generator=gen).to(torch.int32)
-    b_node[0] = 7
+    b_node[0] = min(7, n - 1)
     b_value = torch.randn(n_query, 64, device=dev, generator=gen)
     lib = _lib.load()
     lib.ultra_rspmm_force_general_path(knob)
@@ -92,6 +95,50 @@ def test_fused_layer_equals_rspmm_plus_epilogue(case):
                                                                  w1, b1, w2, b2))
     finally:
         lib.ultra_rspmm_force_general_path(0)
+
+
+def test_fused_layer_keeps_nan_and_inf_where_the_two_launches_do():
+    """Non-finite inputs (a damaged checkpoint): `inf` / `NaN` in the gathered rows and in the relation table travel through the
+    sum, the Linear, LayerNorm and -- `torch.relu` keeps a NaN -- the activation exactly as in the two launches; the score head's
+    relu likewise.  NaN pattern and every other value equal."""
+    from ultra_torchdrug_amd import RelCSR, functional as UF
+    dev = _dev()
+    n, e, r, n_query = 2000, 9000, 12, 2
+    g = random_graph(seed=21, n_node=n, n_edge=e, n_rel=r)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    csr = RelCSR(t(g["dst"]), t(g["src"]), t(g["rel"]), None, n, n, r, wide_ids=True, piece_len=512)
+    gen = torch.Generator(device=dev).manual_seed(8)
+    x = torch.randn(n, n_query, 64, device=dev, generator=gen)
+    x[5, 0, 3] = float("nan")
+    x[9, 1, 60] = float("inf")
+    x[11, 0, :] = float("-inf")
+    relation = torch.randn(r, 64 * n_query, device=dev, generator=gen)
+    relation[4, 70] = float("inf")
+    boundary = (torch.tensor([5, 40], dtype=torch.int32, device=dev), torch.randn(n_query, 64, device=dev, generator=gen))
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0))
+    for layer_norm, relu in ((True, True), (False, True), (True, False)):
+        w, b, gamma, beta = _layer_params(gen, dev, layer_norm)
+        update = UF.rspmm_forward(csr, relation, x.flatten(1), "add", "mul", boundary=boundary).view(n, n_query, 64)
+        want = UF.combine_forward(x, update, w, b, gamma, beta, 1e-5, relu, True)
+        got = UF.layer_forward(csr, relation, x, boundary, w, b, gamma, beta, 1e-5, relu, True)
+        assert got is not None and bool(want.isnan().any()) and not bool(want.isnan().all())
+        assert same(got, want)
+        if relu:        # ... and torch's own chain keeps a NaN at the same places (relu(NaN) = NaN)
+            ref = torch.cat([x, update], dim=-1) @ w.t() + b
+            if layer_norm:
+                ref = torch.nn.functional.layer_norm(ref, (64,), gamma, beta, 1e-5)
+            assert torch.equal((torch.relu(ref) + x).isnan(), want.isnan())
+        query = torch.randn(n_query, 64, device=dev, generator=gen)
+        w1 = torch.randn(128, 128, device=dev, generator=gen) * 0.1
+        b1 = torch.randn(128, device=dev, generator=gen) * 0.1
+        w2 = torch.randn(1, 128, device=dev, generator=gen) * 0.1
+        b2 = torch.randn(1, device=dev, generator=gen)
+        want_score = UF.score_all_entities(want, query, w1, b1, w2, b2)
+        got_score = UF.layer_score_forward(csr, relation, x, boundary, w, b, gamma, beta, 1e-5, relu, True, query, w1, b1, w2, b2)
+        assert got_score is not None and same(got_score, want_score)
+        feature = torch.cat([want.transpose(0, 1), query.unsqueeze(1).expand(-1, n, -1)], dim=-1)
+        ref_score = (torch.relu(feature @ w1.t() + b1) @ w2.t() + b2).squeeze(-1)
+        assert torch.equal(ref_score.isnan(), want_score.isnan())
 
 
 def test_second_layer_with_remapped_sources_equals_the_plain_layer(monkeypatch):
