@@ -692,3 +692,29 @@ def test_engine_evaluate_honours_metric_per_rel_and_validates_ids():
     with pytest.raises(ValueError, match="filter graph has"):
         task.add_context("broken", Graph(torch.from_numpy(triples), num_node=n + 7, num_relation=r),
                          fact_graph=Graph(torch.from_numpy(triples[:300]), num_node=n, num_relation=r))
+
+
+def test_tiled_relation_tables_node_equals_the_per_layer_expand_and_its_autograd():
+    """rel_model._TiledTables (training, relation stack): ``weight.unsqueeze(1).expand(-1, B, -1).flatten(1)`` of every layer
+    (``ultra/layer.py:125-126``) from ONE autograd node -- same tables; gradients = the sum over the B copies, also when a
+    layer's table receives no gradient; and the query rows picked with ``gather`` (model.py) == advanced indexing, values and
+    gradient."""
+    from ultra_torchdrug_amd.rel_model import _TiledTables
+    torch.manual_seed(0)
+    weights = [torch.randn(4, 64, requires_grad=True) for _ in range(6)]
+    tables = _TiledTables.apply(5, *weights)
+    plain = [w.unsqueeze(1).expand(-1, 5, -1).flatten(1) for w in weights]
+    assert len(tables) == 6 and all(torch.equal(a, b) for a, b in zip(tables, plain))
+    upstream = [torch.randn(4, 320) for _ in range(6)]
+    used = (0, 2, 3, 5)                                          # layers 1 and 4 stay without a gradient
+    got = torch.autograd.grad(sum((tables[i] * upstream[i]).sum() for i in used), [weights[i] for i in used])
+    want = torch.autograd.grad(sum((plain[i] * upstream[i]).sum() for i in used), [weights[i] for i in used])
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+    query = torch.randn(7, 9, 64, requires_grad=True)
+    r_index = torch.tensor([0, 8, 3, 3, 1, 5, 2])
+    a = query[torch.arange(7), r_index]
+    b = query.gather(1, r_index.view(7, 1, 1).expand(7, 1, 64)).squeeze(1)
+    assert torch.equal(a, b)
+    g = torch.randn(7, 64)
+    assert torch.equal(torch.autograd.grad(a, query, g)[0], torch.autograd.grad(b, query, g)[0])
