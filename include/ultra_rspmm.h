@@ -355,6 +355,7 @@ int ultra_rspmm_backward_weight_f32(const ultra_segments *fwd_host, const float 
  *   input, update, out : [rows, 64] fp32 (a row = one (node, query) pair);  weight [64, 128] = nn.Linear.weight;
  *                        `out` may be the same buffer as `update` (each 32-row tile is read before it is written);
  *   bias [64];  ln_weight / ln_bias [64] or both NULL (no LayerNorm);  relu, shortcut: 0 / 1.
+ * relu here and in every other forward entry of this header is torch.relu's: a NaN stays a NaN (`!(v <= 0) ? v : 0`).
  * Forward of the epilogue; its backward (training) is ultra_combine_backward_f32 + ultra_combine_dxdu_f32 below.
  */
 int ultra_combine_forward_f32(const float *input, const float *update, const float *weight, const float *bias,
