@@ -1253,6 +1253,9 @@ def main():
         finally:
             task.clear_relation_cache()
         replay_same = replays_equal_eager(graphed)
+        # the same replays once the process has kept the GPU busy for seconds: the clocks settle ~2 % below the first second's
+        # (tools/debug/capture_order_probe.py: the FIRST 300 replays of a process 2.00 ms, every later 300 -- same graph -- 2.04)
+        sustained_ms = wall_ms(lambda i: step(i), 300, warm=20) if graphed is not None else None
         # the relation-graph stack alone (what the step spends outside the entity graph and the score head)
         rel_ms = wall_ms(lambda i: task.relation_representations(shard[:B, 2]), 20, warm=3)
     UF.rspmm_forward = real_forward
@@ -1443,6 +1446,7 @@ def main():
             "workload": "%s N=%d E=%d R=%d B=%d F=%d, 6+6 layers x 64d, predict() tail+head over all entities"
                         % (args.workload, n_node, E, R2, B, F),
             "launch": "eager" if graphed is None else "hipGraph replay per step (engine.GraphedPredict)",
+            "ms_per_step_sustained": sustained_ms,
             "mrr_hip": mrr,                                             # filtered MRR, HIP path, `mrr_queries` seeded test triples
             "mrr_hip_first_batch": first.get("mrr_hip"),                # the same B triples on both paths:
             "mrr_cpu_oracle_first_batch": first.get("mrr_cpu_oracle"),
