@@ -383,6 +383,8 @@ def layer_forward(csr, relation, input, boundary, weight, bias, ln_weight=None, 
     F = n_query * 64
     b_node, b_value = (None, None) if boundary is None else boundary
     tensors = [relation, input, weight, bias] + ([ln_weight, ln_bias] if ln_weight is not None else []) + ([b_value] if b_value is not None else [])
+    if (ln_weight is not None and ln_bias is None) or any(t.numel() != 64 for t in tensors[3:4 + (2 if ln_weight is not None else 0)]):
+        return None                                  # (bias, LayerNorm vectors: 64 entries each -- the kernel reads 64)
     if (tuple(relation.shape) != (n_rel, F) or tuple(weight.shape) != (64, 128)
             or any(t.dtype != torch.float32 or not t.is_cuda or t.device != input.device for t in tensors)
             or (b_node is not None and (b_node.dtype != torch.int32 or tuple(b_node.shape) != (n_query,) or tuple(b_value.shape) != (n_query, 64)))):
@@ -428,6 +430,9 @@ def layer_score_forward(csr, relation, input, boundary, weight, bias, ln_weight,
     b_node, b_value = (None, None) if boundary is None else boundary
     tensors = [relation, input, weight, bias, query, w1, b1, w2, b2] + ([ln_weight, ln_bias] if ln_weight is not None else []) \
         + ([b_value] if b_value is not None else [])
+    if (ln_weight is not None and ln_bias is None) or bias.numel() != 64 or b1.numel() != 128 \
+            or (ln_weight is not None and (ln_weight.numel() != 64 or ln_bias.numel() != 64)):
+        return None
     if (tuple(relation.shape) != (n_rel, F) or tuple(weight.shape) != (64, 128) or tuple(w1.shape) != (128, 128) or w2.numel() != 128
             or b2.numel() != 1 or tuple(query.shape) != (n_query, 64)
             or any(t.dtype != torch.float32 or not t.is_cuda or t.device != input.device for t in tensors)
