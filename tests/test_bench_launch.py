@@ -72,3 +72,22 @@ def test_gpus_2_launches_its_own_ranks_and_times_the_pretraining_step_with_the_r
     five = [c for c in cfg["configs"] if c["config"] == 5][0]
     assert five["all_ranks"]["n_gpus"] == 2 == cfg["cfg5_n_gpus"] and len(five["all_ranks"]["per_rank_ms_per_triple"]) == 2
     assert cfg["cfg5_triples_per_s_all_ranks"] > 0 and five["predict_ms"] > 0
+
+
+def test_a_phase_that_overruns_still_leaves_the_headline_line_of_rank_0():
+    """world > 1: a leg after the timed region that hangs (the first real RCCL run) must not cost the headline -- rank 0 prints
+    the reduced headline as a line marked `partial` before the watchdog exits with code 3; other ranks print nothing."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "p = bench.Phases(int(sys.argv[1]), 2)\n"
+            "p.fallback = {'metric': 'm', 'value': 1.5, 'n_gpus': 2}\n"
+            "p.enter('config 4', 0.2)\n"
+            "time.sleep(5)\n" % ROOT)
+    for rank, lines in ((0, 1), (1, 0)):
+        run = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=120)
+        assert run.returncode == 3, run.stderr[-500:]
+        out = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        assert len(out) == lines
+        if lines:
+            line = json.loads(out[0])
+            assert line["value"] == 1.5 and line["n_gpus"] == 2 and "config 4" in line["partial"]
+    assert "exceeded" in run.stderr
